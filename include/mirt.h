@@ -1,0 +1,169 @@
+/* mirt.h -- C ABI of the MI355X (gfx950) render path.
+ *
+ * Drop-in boundary for the hot path of anthonyebiner/raytracer: everything `PathTracer::raytrace()` does after its
+ * guards (reference include/raytracer/renderer.cuh:136-188: BVH build + flatten, uploads, the `raytrace_cuda` launch,
+ * film read-back) and `PathTracer::save_to_file` (renderer.cuh:103-113).  Plain C: pointers and sizes only, no C++ or
+ * torch types.  The library is libmirt.so (raytracer_amd/csrc); the C++ mirror of the reference's host API that calls
+ * it is include/raytracer_amd/pathtracer.hpp; the binding a reference maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MIRT_E_* code; mirt_last_error() gives the message
+ *     (the reference prints and returns / exit(1)s: renderer.cuh:118-133, util/misc.cuh:33-43);
+ *   - host pointers are caller-owned and only touched during the call; device memory lives behind mirt_scene;
+ *   - one render in flight per process (the reference is single-threaded and blocking too, renderer.cuh:178).
+ *   - the GPU is mandatory: there is no CPU fallback; without a usable HIP device every compute entry point fails with
+ *     MIRT_E_DEVICE.
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRT_OK 0
+#define MIRT_E_ARG (-1)       /* bad argument (null pointer, zero size, batch == 0, ...) */
+#define MIRT_E_DEVICE (-2)    /* HIP error (message has the HIP error string) */
+#define MIRT_E_STATE (-3)     /* scene / camera / lights not set, library not initialised */
+#define MIRT_E_LIMIT (-4)     /* size beyond a documented limit */
+#define MIRT_E_IO (-5)        /* file could not be written / read */
+
+/* BSDF record = the reference's `BSDF` (scene/bsdf.cuh:31-67), 36 bytes: type tag + the union's floats in
+ * declaration order.  type: 0 DIFFUSE {reflectance[3]}  1 EMISSION {radiance[3]}  2 REFLECTION {roughness, reflectance[3]}
+ * 3 REFRACTION {ior, roughness, transmittance[3]}  4 GLASS {ior, roughness, reflectance[3], transmittance[3]}
+ * 5 MICROFACET {alpha, eta[3], k[3]}. */
+typedef struct mirt_bsdf {
+  int32_t type;
+  float p[8];
+} mirt_bsdf;
+
+/* Light record = the reference's `SceneLight` (scene/lights.cuh:8-35), 68 bytes, as its factories store it
+ * (lights.cuh:123-146).  type: 0 AREA {radiance[3], position[3], direction[3] (unit), dim_x[3], dim_y[3], area}
+ * 1 POINT {radiance[3], position[3]}  2 DIRECTIONAL {radiance[3], dir_to_light[3] (unit, = -travel direction)}. */
+typedef struct mirt_light {
+  int32_t type;
+  float p[16];
+} mirt_light;
+
+/* Camera record = the reference's `Camera` (scene/camera.cuh:8-17), 72 bytes; c2w is column major (Matrix3f.cuh:165). */
+typedef struct mirt_camera {
+  float origin[3];
+  float c2w[9];
+  float hFov, vFov, nClip, fClip, aperture, focal_distance;
+} mirt_camera;
+
+/* = the reference's `Parameters` (raytracer.cuh:10-17), 24 bytes, same field order. */
+typedef struct mirt_params {
+  uint32_t samples_per_pixel;
+  uint32_t samples_per_light;
+  uint32_t samples_per_batch;   /* adaptive-stop test every this many samples (raytracer.cuh:115); must be > 0 */
+  float max_tolerance;
+  uint32_t max_ray_depth;
+  uint32_t bvh_node_size;       /* informational here: the leaf size is fixed when the scene is created */
+} mirt_params;
+
+/* What the reference has no knob for.  Zero-initialise for reference behaviour on one GPU. */
+typedef struct mirt_options {
+  uint32_t rng_mode;        /* 0 = reference xorshift32 stream per pixel (util/sampler.cuh:8-15, renderer.cuh:50-51);
+                               1 = counter-based Philox2x32-10 keyed by (pixel, sample, seed): needed for spp slices */
+  uint32_t seed;            /* rng_mode 0: xor-ed into the pixel seed (0 = the reference); rng_mode 1: global seed */
+  uint32_t traversal;       /* 0 = ordered wide-BVH traversal (fast path; see DESIGN.md "tie rule")
+                               1 = wide BVH visited in the reference's DFS order (bit-exact with bvh.cuh:78-107)
+                               2 = the reference's BVH2 walked as the reference does (cross-check) */
+  uint32_t tile_rank;       /* tile partition: this process renders 8x8 tiles t with t % tile_world == tile_rank */
+  uint32_t tile_world;      /* 0 or 1 = whole image */
+  uint32_t sample_begin;    /* rng_mode 1 only: first sample index of this process's spp slice */
+  uint32_t sample_count;    /* rng_mode 1 only: samples in the slice; 0 = samples_per_pixel */
+  uint32_t glass_int_abs;   /* 1 = reproduce the g++ build's integer abs() in GLASS (bsdf.cuh:213) */
+  uint32_t reserved[8];
+} mirt_options;
+
+typedef struct mirt_stats {
+  uint64_t closest_rays;    /* one per iteration of the bounce loop (raytracer.cuh:60-62) */
+  uint64_t shadow_rays;     /* one per light sample per non-delta hit (raytracer.cuh:38-43) */
+  uint64_t paths;           /* camera samples started */
+  uint64_t exact_fallback_rays;   /* rays re-traced by the reference-order kernel (non-finite slab / hit values) */
+  uint32_t iterations;      /* wavefront iterations */
+  uint32_t tonemap_table_exact;
+  double render_ms;         /* first launch -> accumulation buffer complete, device events */
+  double trace_closest_ms, trace_shadow_ms, logic_ms;   /* per-kernel sums, device events */
+  double total_ms;          /* wall: entry -> outputs in host memory */
+} mirt_stats;
+
+typedef struct mirt_scene mirt_scene;
+
+/* Select the HIP device for this process (one process per GPU) and create streams/tables.  Idempotent. */
+int mirt_init(int device);
+void mirt_shutdown(void);
+const char *mirt_last_error(void);
+const char *mirt_version(void);
+
+/* Replaces renderer.cuh:136-146 (BVHAccel ctor bvh.cuh:177-225, to_optimized_bvh bvh.cuh:231-290, to_cuda bvh.cuh:112-145).
+ * tri_pos / tri_nrm: n_tris x 9 floats (p1 p2 p3 / n1 n2 n3, scene/primitives.cuh:23-26); tri_mat: material index per
+ * triangle.  The reference's BVH2 is rebuilt bit for bit on the host (its flat primitive order defines hit indices), then
+ * collapsed into the 128-byte wide nodes the kernels walk. */
+int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, uint32_t n_tris,
+                      const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights, uint32_t n_lights,
+                      uint32_t leaf_size, mirt_scene **out);
+void mirt_scene_destroy(mirt_scene *scene);
+
+/* info[0..7]: bvh2 nodes, bvh2 depth (BVHAccel::get_max_depth, bvh.cuh:297), wide nodes, wide depth, n_tris, n_mats,
+ * n_lights, device bytes / 1024. */
+int mirt_scene_info(const mirt_scene *scene, uint32_t info[8]);
+
+/* The reference-layout BVH2 (BVHNodeOpt, bvh.cuh:12-30: 8 dwords per node) and, per flat primitive slot, the index the
+ * primitive had in the caller's arrays.  For structure parity tests. */
+int mirt_scene_bvh2(const mirt_scene *scene, uint32_t *nodes_out, uint32_t *flat_to_orig);
+
+/* Builds the camera record exactly as the reference's Camera ctor does (scene/camera.cuh:19-36) incl. the
+ * focal_distance == 0 rule of PathTracer::set_camera (renderer.cuh:95-101). */
+int mirt_camera_look_at(const float from[3], const float at[3], const float up[3], float hFov, float vFov, float nClip,
+                        float fClip, float aperture, float focal_distance, mirt_camera *out);
+
+/* Replaces renderer.cuh:148-188 (uploads, raytrace_cuda, from_cuda).  rgb_out: w*h*3 int32 in host memory, row major,
+ * y down, exactly `SampleBuffer::data` (util/image.cuh:9-48).  opts and stats may be NULL. */
+int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mirt_params *params, const mirt_options *opts,
+                uint32_t width, uint32_t height, int32_t *rgb_out, mirt_stats *stats);
+
+/* Same render, but leaves the float accumulation buffer on the device: accum_dev = width*height float4
+ * (sum r, sum g, sum b, divisor) in DEVICE memory owned by the caller (e.g. a torch tensor), pixels this process does not
+ * own are written as zeros, so a plain sum over processes (RCCL reduce) composes tile and spp partitions. */
+int mirt_render_accum(mirt_scene *scene, const mirt_camera *camera, const mirt_params *params,
+                      const mirt_options *opts, uint32_t width, uint32_t height, void *accum_dev, mirt_stats *stats);
+
+/* Film: `color /= divisor; SampleBuffer::update_pixel` (raytracer.cuh:124-125, util/image.cuh:36-48) over a device
+ * accumulation buffer; rgb_out is host memory (w*h*3 int32). */
+int mirt_tonemap(const void *accum_dev, uint32_t width, uint32_t height, int32_t *rgb_out);
+
+/* Parity probe: sample-0 camera ray of every pixel, generated with the reference seed procedure (renderer.cuh:50-51,
+ * raytracer.cuh:101-104) and traced with the selected traversal.  idx_out: flat primitive index (reference order) or -1;
+ * tbits_out: bit pattern of ray.max_t after the traversal.  Host buffers, w*h each. */
+int mirt_primary_hits(mirt_scene *scene, const mirt_camera *camera, const mirt_options *opts, uint32_t width,
+                      uint32_t height, int32_t *idx_out, uint32_t *tbits_out);
+
+/* Parity probe: trace caller-supplied rays.  rays: n x 8 floats (origin[3], direction as given to the reference's Ray
+ * ctor [3], min_t, max_t) (scene/ray.cuh:19-25).  any_hit 0: BVHAccelOpt::intersect (bvh.cuh:78-107) -> idx_out flat
+ * index or -1, tbits_out = bits of max_t, bary_out (n x 2, may be NULL) = the two barycentrics b.y b.z.
+ * any_hit 1: BVHAccelOpt::has_intersection (bvh.cuh:49-76) -> idx_out 1 / -1. */
+int mirt_trace(mirt_scene *scene, const float *rays, uint32_t n, int any_hit, uint32_t traversal, int32_t *idx_out,
+               uint32_t *tbits_out, float *bary_out);
+
+/* Replaces PathTracer::save_to_file (renderer.cuh:103-113) + bitmap_image::save_image (util/bitmap_image.cuh:385-430):
+ * 24-bit BMP, bottom-up rows padded to 4 bytes. */
+int mirt_save_bmp(const char *path, const int32_t *rgb, uint32_t width, uint32_t height);
+
+/* Host-side film function for single values (same table the device kernel uses); for tests. */
+int mirt_tonemap_host(const float *rgb_in, uint32_t n_pixels, int32_t *rgb_out);
+
+/* Host-only structure probe (needs no GPU): runs the same builder mirt_scene_create uses.  counts[4] = BVH2 nodes, BVH2
+ * depth, wide nodes, wide depth.  Any of nodes2_out (8 dwords per node, BVHNodeOpt bvh.cuh:12-30), flat_to_orig (n_tris)
+ * and nodes4_out (32 dwords per 128-byte wide node) may be NULL; call once with NULLs to size them. */
+int mirt_bvh_build_host(const float *tri_pos, uint32_t n_tris, uint32_t leaf_size, uint32_t counts[4],
+                        uint32_t *nodes2_out, uint32_t *flat_to_orig, uint32_t *nodes4_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRT_H */

@@ -35,6 +35,7 @@ using std::abs;
 #endif
 
 #include "raytracer/raytracer.cuh"
+#include "raytracer/util/bitmap_image.cuh"
 
 namespace {
 
@@ -410,6 +411,18 @@ void ref_generate_ray(void *h, float x, float y, uint32_t *seed, float *ray_out)
   r[3] = ray.direction.x; r[4] = ray.direction.y; r[5] = ray.direction.z;
   r[6] = ray.inv_d.x; r[7] = ray.inv_d.y; r[8] = ray.inv_d.z;
   r[9] = ray.min_t; r[10] = ray.max_t;
+}
+
+// PathTracer::save_to_file (renderer.cuh:103-113) minus its log line.
+void ref_save_bmp(const char *path, const int32_t *rgb, uint32_t w, uint32_t h) {
+  bitmap_image image(w, h);
+  for (uint x = 0; x < w; x++) {
+    for (uint y = 0; y < h; y++) {
+      Vector3i color(rgb[3 * (y * w + x)], rgb[3 * (y * w + x) + 1], rgb[3 * (y * w + x) + 2]);
+      image.set_pixel(x, y, color.x, color.y, color.z);
+    }
+  }
+  image.save_image(path);
 }
 
 void ref_sizes(uint32_t *out) {

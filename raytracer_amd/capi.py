@@ -1,0 +1,272 @@
+"""ctypes binding of libmirt.so (include/mirt.h).  Plumbing only: every compute call goes to the HIP library; if the
+library is missing or no GPU is usable the call raises -- there is no Python or CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmirt.so")
+
+SYMBOLS = [
+    "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_version", "mirt_scene_create", "mirt_scene_destroy",
+    "mirt_scene_info", "mirt_scene_bvh2", "mirt_camera_look_at", "mirt_render", "mirt_render_accum", "mirt_tonemap",
+    "mirt_primary_hits", "mirt_trace", "mirt_save_bmp", "mirt_tonemap_host", "mirt_bvh_build_host",
+]
+
+
+class MirtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmirt error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class Bsdf(C.Structure):
+    _fields_ = [("type", C.c_int32), ("p", C.c_float * 8)]
+
+
+class Light(C.Structure):
+    _fields_ = [("type", C.c_int32), ("p", C.c_float * 16)]
+
+
+class CameraRec(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("c2w", C.c_float * 9), ("hFov", C.c_float), ("vFov", C.c_float),
+                ("nClip", C.c_float), ("fClip", C.c_float), ("aperture", C.c_float), ("focal_distance", C.c_float)]
+
+
+class Params(C.Structure):
+    _fields_ = [("samples_per_pixel", C.c_uint32), ("samples_per_light", C.c_uint32), ("samples_per_batch", C.c_uint32),
+                ("max_tolerance", C.c_float), ("max_ray_depth", C.c_uint32), ("bvh_node_size", C.c_uint32)]
+
+
+class Options(C.Structure):
+    _fields_ = [("rng_mode", C.c_uint32), ("seed", C.c_uint32), ("traversal", C.c_uint32), ("tile_rank", C.c_uint32),
+                ("tile_world", C.c_uint32), ("sample_begin", C.c_uint32), ("sample_count", C.c_uint32),
+                ("glass_int_abs", C.c_uint32), ("reserved", C.c_uint32 * 8)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64),
+                ("exact_fallback_rays", C.c_uint64), ("iterations", C.c_uint32), ("tonemap_table_exact", C.c_uint32),
+                ("render_ms", C.c_double), ("trace_closest_ms", C.c_double), ("trace_shadow_ms", C.c_double),
+                ("logic_ms", C.c_double), ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+assert C.sizeof(Bsdf) == 36 and C.sizeof(Light) == 68 and C.sizeof(CameraRec) == 72 and C.sizeof(Params) == 24
+
+_lib = None
+
+
+def load():
+    """Load libmirt.so (built in-tree by raytracer_amd/csrc/Makefile).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: run `make -C raytracer_amd/csrc` (hipcc, gfx950)")
+        lib = C.CDLL(LIB_PATH)
+        lib.mirt_last_error.restype = C.c_char_p
+        lib.mirt_version.restype = C.c_char_p
+        lib.mirt_scene_destroy.restype = None
+        lib.mirt_shutdown.restype = None
+        _lib = lib
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise MirtError(rc, load().mirt_last_error().decode())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def init(device=0):
+    _chk(load().mirt_init(C.c_int(device)))
+
+
+def bsdf_records(mats9):
+    """(M, 9) float rows [type, union floats...] -> array of mirt_bsdf."""
+    mats9 = np.asarray(mats9, np.float32).reshape(-1, 9)
+    rec = np.zeros((len(mats9), 9), np.uint32)
+    rec[:, 0] = mats9[:, 0].astype(np.uint32)
+    rec[:, 1:] = mats9[:, 1:].view(np.uint32)
+    return rec
+
+
+def light_records(lights16):
+    """(L, 16) factory-argument rows -> (L, 17) stored mirt_light records, built as the reference's factories do
+    (scene/lights.cuh:123-146): area direction normalised + area = |dim_x| |dim_y|, directional negated + normalised.
+    Same float32 operation order as linalg/Vector3f.cuh (norm = sqrt(x*x + y*y + z*z), unit = v * float(1/norm))."""
+    lights16 = np.asarray(lights16, np.float32).reshape(-1, 16)
+    f = np.float32
+
+    def norm(v):
+        return np.sqrt(f(f(f(v[0] * v[0]) + f(v[1] * v[1])) + f(v[2] * v[2])), dtype=np.float32)
+
+    def unit(v):
+        rn = f(np.float64(1.0) / np.float64(norm(v)))
+        return np.array([f(v[0] * rn), f(v[1] * rn), f(v[2] * rn)], np.float32)
+
+    out = np.zeros((len(lights16), 17), np.uint32)
+    for i, l in enumerate(lights16):
+        t = int(l[0])
+        p = np.zeros(16, np.float32)
+        a = l[1:]
+        if t == 0:
+            p[0:6] = a[0:6]
+            p[6:9] = unit(a[6:9])
+            p[9:15] = a[9:15]
+            p[15] = f(norm(a[9:12]) * norm(a[12:15]))
+        elif t == 1:
+            p[0:6] = a[0:6]
+        else:
+            t = 2
+            p[0:3] = a[0:3]
+            p[3:6] = unit(-a[3:6])
+        out[i, 0] = t
+        out[i, 1:] = p.view(np.uint32)
+    return out
+
+
+class Scene:
+    """Owns a mirt_scene handle.  Mirrors what PathTracer::set_scene + the BVH part of raytrace() do."""
+
+    def __init__(self, sc, leaf_size=4):
+        lib = load()
+        self.n = sc.n
+        self.mats = bsdf_records(sc.mats)
+        self.lights = light_records(sc.lights)
+        h = C.c_void_p()
+        _chk(lib.mirt_scene_create(_p(sc.pos), _p(sc.nrm), _p(sc.mat), C.c_uint32(sc.n), _p(self.mats),
+                                   C.c_uint32(len(self.mats)), _p(self.lights) if len(self.lights) else None,
+                                   C.c_uint32(len(self.lights)), C.c_uint32(leaf_size), C.byref(h)))
+        self.h = h
+        self.camera = None
+        if sc.camera is not None:
+            self.set_camera(sc.camera)
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().mirt_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        a = (C.c_uint32 * 8)()
+        _chk(load().mirt_scene_info(self.h, a))
+        keys = ["bvh2_nodes", "bvh2_depth", "wide_nodes", "wide_depth", "n_tris", "n_mats", "n_lights", "device_kib"]
+        return dict(zip(keys, list(a)))
+
+    def bvh2(self):
+        n_nodes = self.info()["bvh2_nodes"]
+        nodes = np.zeros((n_nodes, 8), np.uint32)
+        flat = np.zeros(self.n, np.uint32)
+        _chk(load().mirt_scene_bvh2(self.h, _p(nodes), _p(flat)))
+        return nodes, flat
+
+    def set_camera(self, cam):
+        rec = CameraRec()
+        v = lambda t: (C.c_float * 3)(*t)
+        _chk(load().mirt_camera_look_at(v(cam.look_from), v(cam.look_at), v(cam.up), C.c_float(cam.hfov),
+                                        C.c_float(cam.vfov), C.c_float(cam.nclip), C.c_float(cam.fclip),
+                                        C.c_float(cam.aperture), C.c_float(cam.focal), C.byref(rec)))
+        self.camera = rec
+        return rec
+
+    def camera_record(self):
+        return np.frombuffer(bytes(self.camera), np.float32).copy()
+
+    @staticmethod
+    def _params(spp, spl, batch, tol, depth, leaf):
+        return Params(spp, spl, batch, tol, depth, leaf)
+
+    @staticmethod
+    def options(rng_mode=0, seed=0, traversal=0, tile_rank=0, tile_world=1, sample_begin=0, sample_count=0,
+                glass_int_abs=0, profile=False):
+        o = Options()
+        o.rng_mode, o.seed, o.traversal = rng_mode, seed, traversal
+        o.tile_rank, o.tile_world = tile_rank, tile_world
+        o.sample_begin, o.sample_count, o.glass_int_abs = sample_begin, sample_count, glass_int_abs
+        o.reserved[0] = 1 if profile else 0
+        return o
+
+    def render(self, w, h, spp=4, spl=1, batch=64, tol=0.05, depth=4, leaf=4, **opt):
+        prm = self._params(spp, spl, batch, tol, depth, leaf)
+        o = self.options(**opt)
+        st = Stats()
+        rgb = np.zeros((h, w, 3), np.int32)
+        _chk(load().mirt_render(self.h, C.byref(self.camera), C.byref(prm), C.byref(o), C.c_uint32(w), C.c_uint32(h),
+                                _p(rgb), C.byref(st)))
+        self.last = st.as_dict()
+        return rgb
+
+    def render_accum(self, w, h, accum_ptr, spp=4, spl=1, batch=64, tol=0.05, depth=4, leaf=4, **opt):
+        """accum_ptr: integer device address of a w*h*4 float32 buffer (e.g. torch tensor .data_ptr())."""
+        prm = self._params(spp, spl, batch, tol, depth, leaf)
+        o = self.options(**opt)
+        st = Stats()
+        _chk(load().mirt_render_accum(self.h, C.byref(self.camera), C.byref(prm), C.byref(o), C.c_uint32(w),
+                                      C.c_uint32(h), C.c_void_p(accum_ptr), C.byref(st)))
+        self.last = st.as_dict()
+        return self.last
+
+    def primary_hits(self, w, h, **opt):
+        o = self.options(**opt)
+        idx = np.zeros((h, w), np.int32)
+        tb = np.zeros((h, w), np.uint32)
+        _chk(load().mirt_primary_hits(self.h, C.byref(self.camera), C.byref(o), C.c_uint32(w), C.c_uint32(h), _p(idx), _p(tb)))
+        return idx, tb
+
+    def trace(self, rays8, anyhit=False, traversal=0, bary=False):
+        rays8 = np.ascontiguousarray(rays8, np.float32).reshape(-1, 8)
+        n = len(rays8)
+        idx = np.zeros(n, np.int32)
+        tb = np.zeros(n, np.uint32)
+        b = np.zeros((n, 2), np.float32) if bary else None
+        _chk(load().mirt_trace(self.h, _p(rays8), C.c_uint32(n), C.c_int(int(anyhit)), C.c_uint32(traversal), _p(idx),
+                               _p(tb), _p(b)))
+        return (idx, tb, b) if bary else (idx, tb)
+
+
+def bvh_build_host(pos, leaf_size=4):
+    """Host-only structure probe (no GPU needed): the reference-layout BVH2, the flat order and the wide nodes."""
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 9)
+    n = len(pos)
+    cnt = (C.c_uint32 * 4)()
+    _chk(load().mirt_bvh_build_host(_p(pos), C.c_uint32(n), C.c_uint32(leaf_size), cnt, None, None, None))
+    nodes2 = np.zeros((cnt[0], 8), np.uint32)
+    flat = np.zeros(n, np.uint32)
+    nodes4 = np.zeros((cnt[2], 32), np.uint32)
+    _chk(load().mirt_bvh_build_host(_p(pos), C.c_uint32(n), C.c_uint32(leaf_size), cnt, _p(nodes2), _p(flat), _p(nodes4)))
+    return dict(nodes2=nodes2, flat=flat, nodes4=nodes4, depth2=cnt[1], depth4=cnt[3])
+
+
+def tonemap(accum_ptr, w, h):
+    rgb = np.zeros((h, w, 3), np.int32)
+    _chk(load().mirt_tonemap(C.c_void_p(accum_ptr), C.c_uint32(w), C.c_uint32(h), _p(rgb)))
+    return rgb
+
+
+def tonemap_host(rgb_float):
+    a = np.ascontiguousarray(rgb_float, np.float32).reshape(-1, 3)
+    out = np.zeros(a.shape, np.int32)
+    _chk(load().mirt_tonemap_host(_p(a), C.c_uint32(len(a)), _p(out)))
+    return out
+
+
+def save_bmp(path, rgb):
+    rgb = np.ascontiguousarray(rgb, np.int32)
+    h, w, _ = rgb.shape
+    _chk(load().mirt_save_bmp(path.encode(), _p(rgb), C.c_uint32(w), C.c_uint32(h)))

@@ -1,0 +1,709 @@
+// libmirt C ABI (include/mirt.h): host orchestration of the wavefront path tracer.  No CPU fallback anywhere: every
+// compute entry point needs a HIP device and fails with MIRT_E_DEVICE without one.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mirt.h"
+#include "host_bvh.hpp"
+#include "host_film.hpp"
+#include "kernels.hpp"
+
+using namespace mirt;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+static const bool g_debug = getenv("MIRT_DEBUG") != nullptr;
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    if (g_debug) { fprintf(stderr, "[mirt] %s:%d %s\n", __func__, __LINE__, #expr); fflush(stderr); }    \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return fail(MIRT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= bytes && p) return hipSuccess;
+    if (p) (void) hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, n ? n : 16);
+    if (e == hipSuccess) bytes = n ? n : 16;
+    return e;
+  }
+  void release() {
+    if (p) (void) hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template<class T> T *as() const { return (T *) p; }
+};
+
+constexpr int RING = 4;
+
+struct Global {
+  bool ready = false;
+  int device = -1;
+  int n_cu = 0;
+  int blocks_per_cu = 2;
+  hipStream_t stream = nullptr;
+  float table[256];
+  bool table_exact = false;
+  DevBuf d_table;
+  uint32_t *h_counts = nullptr;          // pinned: RING x QC_COUNT
+  hipEvent_t ring_ev[RING] = {};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+} G;
+
+// control block layout (uint32): qcount[4] | work_head[2] | redo_count[2] | error flag
+enum { CTRL_QCOUNT = 0, CTRL_WORK = 4, CTRL_REDO = 6, CTRL_ERR = 8, CTRL_WORDS = 12 };
+
+}  // namespace
+
+struct mirt_scene {
+  HostBVH bvh;
+  uint32_t n_tris = 0, n_mats = 0, n_lights = 0;
+  DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big;
+  uint32_t ovf_depth = 0;
+  uint32_t trace_threads = 0;
+  // work buffers (sized per render)
+  DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2];
+  DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t;
+  size_t device_bytes() const {
+    const DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &st, &mask, &total, &accum, &dmask,
+                           &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0],
+                           &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t};
+    size_t s = 0;
+    for (auto *b: all) s += b->bytes;
+    return s;
+  }
+  void release_all() {
+    DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &st, &mask, &total, &accum, &dmask,
+                     &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0], &redo_q[1],
+                     &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t};
+    for (auto *b: all) b->release();
+  }
+};
+
+extern "C" {
+
+const char *mirt_last_error(void) { return g_err.c_str(); }
+const char *mirt_version(void) { return "mirt 0.1 (gfx950 wavefront path tracer)"; }
+
+int mirt_init(int device) {
+  if (G.ready && G.device == device) return MIRT_OK;
+  if (G.ready) mirt_shutdown();
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(MIRT_E_DEVICE, "no HIP device available (libmirt has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(MIRT_E_ARG, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  G.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIPCHK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
+  G.table_exact = build_tonemap_table(G.table);
+  HIPCHK(G.d_table.ensure(sizeof(G.table)));
+  HIPCHK(hipMemcpy(G.d_table.p, G.table, sizeof(G.table), hipMemcpyHostToDevice));
+  HIPCHK(hipHostMalloc((void **) &G.h_counts, RING * QC_COUNT * sizeof(uint32_t), hipHostMallocDefault));
+  for (int i = 0; i < RING; i++) HIPCHK(hipEventCreateWithFlags(&G.ring_ev[i], hipEventDisableTiming));
+  HIPCHK(hipEventCreate(&G.ev0));
+  HIPCHK(hipEventCreate(&G.ev1));
+  G.blocks_per_cu = trace4_blocks_per_cu();
+  if (const char *s = getenv("MIRT_BLOCKS_PER_CU")) {
+    int v = atoi(s);
+    if (v >= 1 && v <= 16) G.blocks_per_cu = v;
+  }
+  G.device = device;
+  G.ready = true;
+  return MIRT_OK;
+}
+
+void mirt_shutdown(void) {
+  if (!G.ready) return;
+  (void) hipStreamSynchronize(G.stream);
+  for (int i = 0; i < RING; i++) if (G.ring_ev[i]) (void) hipEventDestroy(G.ring_ev[i]);
+  if (G.ev0) (void) hipEventDestroy(G.ev0);
+  if (G.ev1) (void) hipEventDestroy(G.ev1);
+  if (G.h_counts) (void) hipHostFree(G.h_counts);
+  G.d_table.release();
+  (void) hipStreamDestroy(G.stream);
+  G = Global();
+}
+
+int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, uint32_t n_tris,
+                      const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights, uint32_t n_lights,
+                      uint32_t leaf_size, mirt_scene **out) {
+  if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
+  if (!out) return fail(MIRT_E_ARG, "out is null");
+  *out = nullptr;
+  if (!tri_pos || !tri_nrm || !tri_mat || n_tris == 0) return fail(MIRT_E_ARG, "SCENE NOT SET!");          // renderer.cuh:122
+  if (!mats || n_mats == 0) return fail(MIRT_E_ARG, "no materials");
+  if (n_lights && !lights) return fail(MIRT_E_ARG, "lights is null");
+  for (uint32_t i = 0; i < n_tris; i++)
+    if (tri_mat[i] >= n_mats) return fail(MIRT_E_ARG, "material index out of range");
+  auto *s = new mirt_scene();
+  try {
+    build_reference_bvh2(tri_pos, n_tris, leaf_size, s->bvh);
+    collapse_to_wide(s->bvh);
+  } catch (const std::exception &ex) {
+    delete s;
+    return fail(MIRT_E_LIMIT, ex.what());
+  }
+  if (s->bvh.depth2 + 2 > (uint32_t) BVH2_STACK) {
+    delete s;
+    return fail(MIRT_E_LIMIT, "reference BVH deeper than the traversal stack (62 levels)");
+  }
+  s->n_tris = n_tris;
+  s->n_mats = n_mats;
+  s->n_lights = n_lights;
+
+  // triangles in the reference's flat order: (p1, e1, e2) for the intersector, (n1, n2, n3, material, original id) for shading
+  std::vector<float> tri((size_t) n_tris * 12), nrm((size_t) n_tris * 12);
+  for (uint32_t f = 0; f < n_tris; f++) {
+    const uint32_t o = s->bvh.flat_to_orig[f];
+    const float *p = tri_pos + 9 * (size_t) o, *q = tri_nrm + 9 * (size_t) o;
+    float *t = &tri[(size_t) f * 12], *m = &nrm[(size_t) f * 12];
+    t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
+    t[3] = p[3] - p[0]; t[4] = p[4] - p[1]; t[5] = p[5] - p[2];       // e1 = p2 - p1 (primitives.cuh:138)
+    t[6] = p[6] - p[0]; t[7] = p[7] - p[1]; t[8] = p[8] - p[2];       // e2 = p3 - p1 (primitives.cuh:139)
+    t[9] = t[10] = t[11] = 0.f;
+    memcpy(m, q, 9 * sizeof(float));
+    memcpy(m + 9, &tri_mat[o], 4);
+    memcpy(m + 10, &o, 4);
+    m[11] = 0.f;
+  }
+  int rc = MIRT_OK;
+  auto up = [&](DevBuf &b, const void *src, size_t bytes) -> bool {
+    if (b.ensure(bytes) != hipSuccess) return false;
+    return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  bool ok = up(s->tris, tri.data(), tri.size() * 4) && up(s->tri_nrm, nrm.data(), nrm.size() * 4) &&
+            up(s->nodes4, s->bvh.nodes4.data(), s->bvh.nodes4.size() * sizeof(Node4)) &&
+            up(s->nodes2, s->bvh.nodes2.data(), s->bvh.nodes2.size() * sizeof(Node2)) &&
+            up(s->mats, mats, (size_t) n_mats * sizeof(mirt_bsdf)) &&
+            up(s->big, s->bvh.big.empty() ? (const void *) mats : (const void *) s->bvh.big.data(), s->bvh.big.empty() ? 8 : s->bvh.big.size() * 4) &&
+            up(s->lights, lights ? (const void *) lights : (const void *) mats, n_lights ? (size_t) n_lights * sizeof(mirt_light) : 4);
+  if (ok) {
+    s->trace_threads = (uint32_t) (G.n_cu * G.blocks_per_cu * TRACE_BLOCK);
+    int need = 3 * ((int) s->bvh.depth4 + 2) - LDS_STACK + 1;
+    s->ovf_depth = (uint32_t) (need > 1 ? need : 1);
+    ok = s->ovf.ensure((size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
+  }
+  if (!ok) {
+    rc = fail(MIRT_E_DEVICE, std::string("scene upload failed: ") + hipGetErrorString(hipGetLastError()));
+    s->release_all();
+    delete s;
+    return rc;
+  }
+  *out = s;
+  return MIRT_OK;
+}
+
+void mirt_scene_destroy(mirt_scene *s) {
+  if (!s) return;
+  if (G.ready) (void) hipStreamSynchronize(G.stream);
+  s->release_all();
+  delete s;
+}
+
+int mirt_scene_info(const mirt_scene *s, uint32_t info[8]) {
+  if (!s || !info) return fail(MIRT_E_ARG, "null argument");
+  info[0] = (uint32_t) s->bvh.nodes2.size();
+  info[1] = s->bvh.depth2;
+  info[2] = (uint32_t) s->bvh.nodes4.size();
+  info[3] = s->bvh.depth4;
+  info[4] = s->n_tris;
+  info[5] = s->n_mats;
+  info[6] = s->n_lights;
+  info[7] = (uint32_t) (s->device_bytes() / 1024);
+  return MIRT_OK;
+}
+
+int mirt_scene_bvh2(const mirt_scene *s, uint32_t *nodes_out, uint32_t *flat_to_orig) {
+  if (!s) return fail(MIRT_E_ARG, "null scene");
+  if (nodes_out) memcpy(nodes_out, s->bvh.nodes2.data(), s->bvh.nodes2.size() * sizeof(Node2));
+  if (flat_to_orig) memcpy(flat_to_orig, s->bvh.flat_to_orig.data(), s->bvh.flat_to_orig.size() * 4);
+  return MIRT_OK;
+}
+
+// host restatement of the Camera ctor (scene/camera.cuh:19-36); same float operations as linalg/Vector3f.cuh
+int mirt_camera_look_at(const float from[3], const float at[3], const float up[3], float hFov, float vFov, float nClip,
+                        float fClip, float aperture, float focal_distance, mirt_camera *out) {
+  if (!from || !at || !up || !out) return fail(MIRT_E_ARG, "null argument");
+  auto sub = [](const float *a, const float *b, float *r) { for (int i = 0; i < 3; i++) r[i] = a[i] - b[i]; };
+  auto cross = [](const float *a, const float *b, float *r) {
+    r[0] = a[1] * b[2] - a[2] * b[1];
+    r[1] = a[2] * b[0] - a[0] * b[2];
+    r[2] = a[0] * b[1] - a[1] * b[0];
+  };
+  auto norm = [](const float *a) { return (float) std::sqrt((double) (a[0] * a[0] + a[1] * a[1] + a[2] * a[2])); };
+  auto unit = [&](const float *a, float *r) {
+    float rn = (float) (1. / (double) norm(a));
+    for (int i = 0; i < 3; i++) r[i] = a[i] * rn;
+  };
+  float d[3], x[3], y[3], t[3];
+  sub(from, at, d);
+  if (focal_distance == 0) focal_distance = norm(d);                     // renderer.cuh:97-99
+  cross(up, d, t);
+  unit(t, x);
+  cross(d, x, t);
+  unit(t, y);
+  for (int i = 0; i < 3; i++) {
+    out->origin[i] = from[i];
+    out->c2w[i] = x[i];
+    out->c2w[3 + i] = y[i];
+  }
+  unit(d, out->c2w + 6);
+  out->hFov = hFov; out->vFov = vFov; out->nClip = nClip; out->fClip = fClip;
+  out->aperture = aperture; out->focal_distance = focal_distance;
+  return MIRT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+DCamera to_device_camera(const mirt_camera &c) {
+  DCamera d;
+  d.origin = {c.origin[0], c.origin[1], c.origin[2]};
+  d.c2w.c0 = {c.c2w[0], c.c2w[1], c.c2w[2]};
+  d.c2w.c1 = {c.c2w[3], c.c2w[4], c.c2w[5]};
+  d.c2w.c2 = {c.c2w[6], c.c2w[7], c.c2w[8]};
+  const float PI_F = 3.14159265358979323f;
+  d.tan_h = tanf(c.hFov * PI_F / 360);                                   // camera.cuh:39, host libm like the oracle
+  d.tan_v = tanf(c.vFov * PI_F / 360);
+  d.nClip = c.nClip; d.fClip = c.fClip; d.aperture = c.aperture; d.focal_distance = c.focal_distance;
+  return d;
+}
+
+struct Partition {
+  uint32_t tiles_x, tiles_y, rank, world, n_slots;
+};
+Partition make_partition(uint32_t w, uint32_t h, const mirt_options &o) {
+  Partition p;
+  p.tiles_x = (w + 7) / 8;
+  p.tiles_y = (h + 7) / 8;
+  p.world = o.tile_world ? o.tile_world : 1;
+  p.rank = o.tile_rank;
+  const uint64_t total = (uint64_t) p.tiles_x * p.tiles_y;
+  const uint64_t local = total > p.rank ? (total - p.rank + p.world - 1) / p.world : 0;
+  p.n_slots = (uint32_t) (local * 64);
+  return p;
+}
+
+int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
+  const size_t n = n_slots ? n_slots : 64, kn = (size_t) (K ? K : 1) * n;
+  HIPCHK(s->st.ensure(n * 16));
+  HIPCHK(s->mask.ensure(n * 16));
+  HIPCHK(s->total.ensure(n * 16));
+  HIPCHK(s->accum.ensure(n * 16));
+  HIPCHK(s->dmask.ensure(n * 16));
+  HIPCHK(s->ray_o.ensure(n * 16));
+  HIPCHK(s->ray_d.ensure(n * 16));
+  HIPCHK(s->hit.ensure(n * 16));
+  HIPCHK(s->sh_o.ensure(kn * 16));
+  HIPCHK(s->sh_d.ensure(kn * 16));
+  HIPCHK(s->sh_c.ensure(kn * 16));
+  HIPCHK(s->sh_occ.ensure(kn * 4));
+  HIPCHK(s->ext_queue.ensure(n * 4));
+  HIPCHK(s->sh_queue.ensure(kn * 4));
+  HIPCHK(s->redo_q[0].ensure(n * 4));
+  HIPCHK(s->redo_q[1].ensure(kn * 4));
+  HIPCHK(s->ctrl.ensure(CTRL_WORDS * 4));
+  HIPCHK(s->ray_stats.ensure(4 * 8));
+  return MIRT_OK;
+}
+
+TraceArgs closest_args(mirt_scene *s, uint32_t n_slots) {
+  TraceArgs t;
+  memset(&t, 0, sizeof t);
+  uint32_t *ctrl = s->ctrl.as<uint32_t>();
+  t.nodes4 = s->nodes4.as<float4>();
+  t.nodes2 = s->nodes2.as<float4>();
+  t.tris = s->tris.as<float4>();
+  t.big = s->big.as<uint2>();
+  t.ray_o = s->ray_o.as<float4>();
+  t.ray_d = s->ray_d.as<float4>();
+  t.queue = s->ext_queue.as<uint32_t>();
+  t.qcount = ctrl + CTRL_QCOUNT;
+  t.qc_front = QC_EXT_FRONT;
+  t.qc_back = QC_EXT_BACK;
+  t.qcap = n_slots;
+  t.hit = s->hit.as<float4>();
+  t.work_head = ctrl + CTRL_WORK + 0;
+  t.ovf = s->ovf.as<uint2>();
+  t.ovf_depth = s->ovf_depth;
+  t.redo_queue = s->redo_q[0].as<uint32_t>();
+  t.redo_count = ctrl + CTRL_REDO + 0;
+  t.error_flag = ctrl + CTRL_ERR;
+  t.redo_stat = s->ray_stats.as<unsigned long long>() + 3;
+  return t;
+}
+TraceArgs shadow_args(mirt_scene *s) {
+  TraceArgs t;
+  memset(&t, 0, sizeof t);
+  uint32_t *ctrl = s->ctrl.as<uint32_t>();
+  t.nodes4 = s->nodes4.as<float4>();
+  t.nodes2 = s->nodes2.as<float4>();
+  t.tris = s->tris.as<float4>();
+  t.big = s->big.as<uint2>();
+  t.ray_o = s->sh_o.as<float4>();
+  t.ray_d = s->sh_d.as<float4>();
+  t.queue = s->sh_queue.as<uint32_t>();
+  t.qcount = ctrl + CTRL_QCOUNT;
+  t.qc_front = QC_SHADOW;
+  t.qc_back = -1;
+  t.occ = s->sh_occ.as<uint32_t>();
+  t.work_head = ctrl + CTRL_WORK + 1;
+  t.ovf = s->ovf.as<uint2>();
+  t.ovf_depth = s->ovf_depth;
+  t.redo_queue = s->redo_q[1].as<uint32_t>();
+  t.redo_count = ctrl + CTRL_REDO + 1;
+  t.error_flag = ctrl + CTRL_ERR;
+  t.redo_stat = s->ray_stats.as<unsigned long long>() + 3;
+  return t;
+}
+
+int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, double *ms_acc) {
+  const uint32_t grid = s->trace_threads / TRACE_BLOCK;
+  if (ms_acc) HIPCHK(hipEventRecord(G.ev0, G.stream));
+  HIPCHK(launch_trace(t, any, traversal, grid, G.stream));
+  if (traversal != 2) {
+    t.redo = 1;
+    HIPCHK(launch_trace(t, any, 2, 256, G.stream));
+  }
+  if (ms_acc) {
+    HIPCHK(hipEventRecord(G.ev1, G.stream));
+    HIPCHK(hipEventSynchronize(G.ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, G.ev0, G.ev1));
+    *ms_acc += ms;
+  }
+  return MIRT_OK;
+}
+
+int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm, const mirt_options *opts_in,
+                uint32_t w, uint32_t h, void *accum_dev, mirt_stats *stats) {
+  if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
+  if (!s) return fail(MIRT_E_STATE, "SCENE NOT SET!");                     // renderer.cuh:122
+  if (!camera) return fail(MIRT_E_STATE, "CAMERA NOT SET!");               // renderer.cuh:118
+  if (s->n_lights == 0) return fail(MIRT_E_STATE, "LIGHTS NOT SET!");      // renderer.cuh:126
+  if (w == 0 || h == 0) return fail(MIRT_E_STATE, "SAMPLE BUFFER EMPTY");  // renderer.cuh:130
+  if (!prm || !accum_dev) return fail(MIRT_E_ARG, "null argument");
+  if (prm->samples_per_batch == 0) return fail(MIRT_E_ARG, "samples_per_batch must be > 0 (the reference divides by it)");
+  if ((uint64_t) w * h >= (1ull << 31)) return fail(MIRT_E_LIMIT, "image larger than 2^31 pixels");
+  mirt_options o;
+  memset(&o, 0, sizeof o);
+  if (opts_in) o = *opts_in;
+  if (o.rng_mode > 1 || o.traversal > 2) return fail(MIRT_E_ARG, "bad rng_mode / traversal");
+  if (o.tile_world > 1 && o.tile_rank >= o.tile_world) return fail(MIRT_E_ARG, "tile_rank >= tile_world");
+  const bool sliced = o.sample_count != 0 || o.sample_begin != 0;
+  if (sliced && o.rng_mode != 1) return fail(MIRT_E_ARG, "spp slices need rng_mode 1 (the xorshift stream is sequential per pixel)");
+  const uint64_t K64 = (uint64_t) s->n_lights * prm->samples_per_light;
+  if (K64 > 0xFFFF) return fail(MIRT_E_LIMIT, "more than 65535 shadow rays per hit");
+  const uint32_t K = (uint32_t) K64;
+  const Partition part = make_partition(w, h, o);
+  if ((uint64_t) part.n_slots * (K ? K : 1) >= (1ull << 32)) return fail(MIRT_E_LIMIT, "shadow queue beyond 2^32 entries");
+  auto wall0 = std::chrono::steady_clock::now();
+
+  int rc = ensure_work(s, part.n_slots, K);
+  if (rc) return rc;
+
+  RenderArgs a;
+  memset(&a, 0, sizeof a);
+  a.n_slots = part.n_slots; a.width = w; a.height = h;
+  a.tiles_x = part.tiles_x; a.tiles_y = part.tiles_y; a.tile_rank = part.rank; a.tile_world = part.world;
+  a.rng_mode = o.rng_mode; a.seed = o.seed; a.sample_begin = o.sample_begin;
+  a.spp = o.sample_count ? o.sample_count : prm->samples_per_pixel;
+  a.spl = prm->samples_per_light; a.batch = prm->samples_per_batch; a.max_depth = prm->max_ray_depth;
+  a.adaptive = sliced ? 0 : 1;
+  a.glass_int_abs = o.glass_int_abs; a.n_lights = s->n_lights; a.tol = prm->max_tolerance;
+  a.cam = to_device_camera(*camera);
+  a.st = s->st.as<uint4>(); a.mask = s->mask.as<float4>(); a.total = s->total.as<float4>();
+  a.accum = s->accum.as<float4>(); a.dmask = s->dmask.as<float4>();
+  a.ray_o = s->ray_o.as<float4>(); a.ray_d = s->ray_d.as<float4>(); a.hit = s->hit.as<float4>();
+  a.sh_o = s->sh_o.as<float4>(); a.sh_d = s->sh_d.as<float4>(); a.sh_c = s->sh_c.as<float4>();
+  a.sh_occ = s->sh_occ.as<uint32_t>();
+  a.ext_queue = s->ext_queue.as<uint32_t>(); a.sh_queue = s->sh_queue.as<uint32_t>();
+  uint32_t *ctrl = s->ctrl.as<uint32_t>();
+  a.qcount = ctrl + CTRL_QCOUNT;
+  a.ray_stats = s->ray_stats.as<unsigned long long>();
+  a.out_accum = (float4 *) accum_dev;
+  a.tri_nrm = s->tri_nrm.as<float4>(); a.mats = s->mats.as<float>(); a.lights = s->lights.as<float>();
+
+  const bool profile = stats && (o.reserved[0] & 1u);
+  double ms_closest = 0, ms_shadow = 0, ms_logic = 0;
+  hipEvent_t evA, evB;
+  HIPCHK(hipEventCreate(&evA));
+  HIPCHK(hipEventCreate(&evB));
+
+  HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
+  HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, 32, G.stream));
+  HIPCHK(hipMemsetAsync(s->ctrl.p, 0, CTRL_WORDS * 4, G.stream));
+  HIPCHK(hipEventRecord(evA, G.stream));
+  uint32_t iters = 0;
+  if (part.n_slots) {
+    HIPCHK(launch_init(a, G.stream));
+    const uint64_t max_iters = (uint64_t) a.spp * ((uint64_t) a.max_depth + 3) + 8;
+    const TraceArgs tc = closest_args(s, part.n_slots), ts = shadow_args(s);
+    bool done = false;
+    for (uint64_t it = 0; !done; it++) {
+      if (it >= max_iters + RING) {
+        (void) hipStreamSynchronize(G.stream);
+        return fail(MIRT_E_DEVICE, "wavefront loop did not terminate");
+      }
+      HIPCHK(hipMemsetAsync(ctrl, 0, CTRL_ERR * 4, G.stream));          // queue counters, work heads, redo counters
+      if (profile) HIPCHK(hipEventRecord(G.ev0, G.stream));
+      HIPCHK(launch_logic(a, G.stream));
+      if (profile) {
+        HIPCHK(hipEventRecord(G.ev1, G.stream));
+        HIPCHK(hipEventSynchronize(G.ev1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, G.ev0, G.ev1));
+        ms_logic += ms;
+      }
+      const int slot = (int) (it % RING);
+      HIPCHK(hipMemcpyAsync(G.h_counts + slot * QC_COUNT, ctrl + CTRL_QCOUNT, QC_COUNT * 4, hipMemcpyDeviceToHost, G.stream));
+      HIPCHK(hipEventRecord(G.ring_ev[slot], G.stream));
+      rc = run_trace(s, tc, false, o.traversal, profile ? &ms_closest : nullptr);
+      if (rc) return rc;
+      if (K) {
+        rc = run_trace(s, ts, true, o.traversal, profile ? &ms_shadow : nullptr);
+        if (rc) return rc;
+      }
+      iters++;
+      if (it + 1 >= RING - 1) {                                          // look at the counters of RING-2 iterations ago
+        const uint64_t old = it + 1 - (RING - 1);
+        const int oslot = (int) (old % RING);
+        HIPCHK(hipEventSynchronize(G.ring_ev[oslot]));
+        if (G.h_counts[oslot * QC_COUNT + QC_ACTIVE] == 0) done = true;
+      }
+    }
+  }
+  HIPCHK(hipEventRecord(evB, G.stream));
+  HIPCHK(hipEventSynchronize(evB));
+  uint32_t err = 0;
+  HIPCHK(hipMemcpy(&err, ctrl + CTRL_ERR, 4, hipMemcpyDeviceToHost));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, evA, evB));
+  (void) hipEventDestroy(evA);
+  (void) hipEventDestroy(evB);
+  if (err) return fail(MIRT_E_LIMIT, "traversal stack overflow on the device (BVH too deep)");
+  if (stats) {
+    unsigned long long rs[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(rs, s->ray_stats.p, 32, hipMemcpyDeviceToHost));
+    memset(stats, 0, sizeof *stats);
+    stats->closest_rays = rs[0];
+    stats->shadow_rays = rs[1];
+    stats->paths = rs[2];
+    stats->exact_fallback_rays = rs[3];
+    stats->iterations = iters;
+    stats->tonemap_table_exact = G.table_exact ? 1 : 0;
+    stats->render_ms = ms;
+    stats->trace_closest_ms = ms_closest;
+    stats->trace_shadow_ms = ms_shadow;
+    stats->logic_ms = ms_logic;
+    stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  }
+  return MIRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mirt_render_accum(mirt_scene *scene, const mirt_camera *camera, const mirt_params *params,
+                      const mirt_options *opts, uint32_t width, uint32_t height, void *accum_dev, mirt_stats *stats) {
+  return render_impl(scene, camera, params, opts, width, height, accum_dev, stats);
+}
+
+int mirt_tonemap(const void *accum_dev, uint32_t width, uint32_t height, int32_t *rgb_out) {
+  if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
+  if (!accum_dev || !rgb_out || !width || !height) return fail(MIRT_E_ARG, "null / empty argument");
+  const size_t n = (size_t) width * height;
+  DevBuf rgb;
+  HIPCHK(rgb.ensure(n * 12));
+  hipError_t e = launch_tonemap(accum_dev, (uint32_t) n, G.d_table.as<float>(), rgb.as<int32_t>(), G.stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(rgb_out, rgb.p, n * 12, hipMemcpyDeviceToHost, G.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(G.stream);
+  rgb.release();
+  if (e != hipSuccess) return fail(MIRT_E_DEVICE, std::string("tonemap: ") + hipGetErrorString(e));
+  return MIRT_OK;
+}
+
+int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mirt_params *params, const mirt_options *opts,
+                uint32_t width, uint32_t height, int32_t *rgb_out, mirt_stats *stats) {
+  if (!rgb_out) return fail(MIRT_E_ARG, "rgb_out is null");
+  if (!scene) return fail(MIRT_E_STATE, "SCENE NOT SET!");
+  if (width == 0 || height == 0) return fail(MIRT_E_STATE, "SAMPLE BUFFER EMPTY");
+  auto wall0 = std::chrono::steady_clock::now();
+  HIPCHK(scene->out_accum.ensure((size_t) width * height * 16));
+  int rc = render_impl(scene, camera, params, opts, width, height, scene->out_accum.p, stats);
+  if (rc) return rc;
+  rc = mirt_tonemap(scene->out_accum.p, width, height, rgb_out);
+  if (rc) return rc;
+  if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  return MIRT_OK;
+}
+
+int mirt_primary_hits(mirt_scene *s, const mirt_camera *camera, const mirt_options *opts_in, uint32_t w, uint32_t h,
+                      int32_t *idx_out, uint32_t *tbits_out) {
+  if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
+  if (!s || !camera || !idx_out || !tbits_out || !w || !h) return fail(MIRT_E_ARG, "null / empty argument");
+  mirt_options o;
+  memset(&o, 0, sizeof o);
+  if (opts_in) o = *opts_in;
+  if (o.rng_mode > 1 || o.traversal > 2) return fail(MIRT_E_ARG, "bad rng_mode / traversal");
+  o.tile_rank = 0;
+  o.tile_world = 1;
+  const Partition part = make_partition(w, h, o);
+  int rc = ensure_work(s, part.n_slots, 0);
+  if (rc) return rc;
+  const size_t n = (size_t) w * h;
+  HIPCHK(s->probe_idx.ensure(n * 4));
+  HIPCHK(s->probe_t.ensure(n * 4));
+  RenderArgs a;
+  memset(&a, 0, sizeof a);
+  a.n_slots = part.n_slots; a.width = w; a.height = h;
+  a.tiles_x = part.tiles_x; a.tiles_y = part.tiles_y; a.tile_rank = 0; a.tile_world = 1;
+  a.rng_mode = o.rng_mode; a.seed = o.seed; a.spp = 1; a.batch = 2;
+  a.cam = to_device_camera(*camera);
+  a.st = s->st.as<uint4>(); a.mask = s->mask.as<float4>(); a.total = s->total.as<float4>();
+  a.accum = s->accum.as<float4>(); a.ray_o = s->ray_o.as<float4>(); a.ray_d = s->ray_d.as<float4>();
+  a.hit = s->hit.as<float4>(); a.ext_queue = s->ext_queue.as<uint32_t>();
+  uint32_t *ctrl = s->ctrl.as<uint32_t>();
+  a.qcount = ctrl + CTRL_QCOUNT;
+  HIPCHK(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, G.stream));
+  HIPCHK(launch_init(a, G.stream));
+  HIPCHK(launch_probe_primary(a, G.stream));
+  rc = run_trace(s, closest_args(s, part.n_slots), false, o.traversal, nullptr);
+  if (rc) return rc;
+  HIPCHK(launch_gather_primary(a, s->probe_idx.as<int32_t>(), s->probe_t.as<uint32_t>(), G.stream));
+  HIPCHK(hipMemcpyAsync(idx_out, s->probe_idx.p, n * 4, hipMemcpyDeviceToHost, G.stream));
+  HIPCHK(hipMemcpyAsync(tbits_out, s->probe_t.p, n * 4, hipMemcpyDeviceToHost, G.stream));
+  HIPCHK(hipStreamSynchronize(G.stream));
+  uint32_t err = 0;
+  HIPCHK(hipMemcpy(&err, ctrl + CTRL_ERR, 4, hipMemcpyDeviceToHost));
+  if (err) return fail(MIRT_E_LIMIT, "traversal stack overflow on the device (BVH too deep)");
+  return MIRT_OK;
+}
+
+int mirt_trace(mirt_scene *s, const float *rays, uint32_t n, int any_hit, uint32_t traversal, int32_t *idx_out,
+               uint32_t *tbits_out, float *bary_out) {
+  if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
+  if (!s || !idx_out || !tbits_out) return fail(MIRT_E_ARG, "null argument");
+  if (traversal > 2) return fail(MIRT_E_ARG, "bad traversal");
+  if (n == 0) return MIRT_OK;
+  if (!rays) return fail(MIRT_E_ARG, "rays is null");
+  int rc = ensure_work(s, n, 1);
+  if (rc) return rc;
+  std::vector<float> ro((size_t) n * 4), rd((size_t) n * 4);
+  for (uint32_t i = 0; i < n; i++) {
+    const float *r = rays + 8 * (size_t) i;
+    ro[4 * (size_t) i + 0] = r[0]; ro[4 * (size_t) i + 1] = r[1]; ro[4 * (size_t) i + 2] = r[2]; ro[4 * (size_t) i + 3] = r[6];
+    rd[4 * (size_t) i + 0] = r[3]; rd[4 * (size_t) i + 1] = r[4]; rd[4 * (size_t) i + 2] = r[5]; rd[4 * (size_t) i + 3] = r[7];
+  }
+  uint32_t *ctrl = s->ctrl.as<uint32_t>();
+  HIPCHK(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, G.stream));
+  TraceArgs t;
+  if (any_hit) {
+    HIPCHK(s->any_t.ensure((size_t) n * 4));
+    HIPCHK(hipMemcpyAsync(s->sh_o.p, ro.data(), (size_t) n * 16, hipMemcpyHostToDevice, G.stream));
+    HIPCHK(hipMemcpyAsync(s->sh_d.p, rd.data(), (size_t) n * 16, hipMemcpyHostToDevice, G.stream));
+    HIPCHK(launch_iota(s->sh_queue.as<uint32_t>(), n, G.stream));
+    HIPCHK(hipMemcpyAsync(ctrl + CTRL_QCOUNT + QC_SHADOW, &n, 4, hipMemcpyHostToDevice, G.stream));
+    t = shadow_args(s);
+    t.any_t = s->any_t.as<float>();
+  } else {
+    HIPCHK(hipMemcpyAsync(s->ray_o.p, ro.data(), (size_t) n * 16, hipMemcpyHostToDevice, G.stream));
+    HIPCHK(hipMemcpyAsync(s->ray_d.p, rd.data(), (size_t) n * 16, hipMemcpyHostToDevice, G.stream));
+    HIPCHK(launch_iota(s->ext_queue.as<uint32_t>(), n, G.stream));
+    HIPCHK(hipMemcpyAsync(ctrl + CTRL_QCOUNT + QC_EXT_FRONT, &n, 4, hipMemcpyHostToDevice, G.stream));
+    t = closest_args(s, n);
+  }
+  HIPCHK(hipStreamSynchronize(G.stream));     // the host staging vectors and &n must outlive the copies
+  rc = run_trace(s, t, any_hit != 0, traversal, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(G.stream));
+  if (any_hit) {
+    std::vector<uint32_t> occ(n);
+    std::vector<float> tt(n);
+    HIPCHK(hipMemcpy(occ.data(), s->sh_occ.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tt.data(), s->any_t.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) {
+      idx_out[i] = occ[i] ? 1 : -1;
+      memcpy(&tbits_out[i], &tt[i], 4);
+    }
+  } else {
+    std::vector<float> hit((size_t) n * 4);
+    HIPCHK(hipMemcpy(hit.data(), s->hit.p, (size_t) n * 16, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) {
+      memcpy(&tbits_out[i], &hit[4 * (size_t) i], 4);
+      memcpy(&idx_out[i], &hit[4 * (size_t) i + 3], 4);
+      if (bary_out) {
+        bary_out[2 * (size_t) i] = hit[4 * (size_t) i + 1];
+        bary_out[2 * (size_t) i + 1] = hit[4 * (size_t) i + 2];
+      }
+    }
+  }
+  uint32_t err = 0;
+  HIPCHK(hipMemcpy(&err, ctrl + CTRL_ERR, 4, hipMemcpyDeviceToHost));
+  if (err) return fail(MIRT_E_LIMIT, "traversal stack overflow on the device (BVH too deep)");
+  return MIRT_OK;
+}
+
+int mirt_save_bmp(const char *path, const int32_t *rgb, uint32_t width, uint32_t height) {
+  if (!path || !rgb || !width || !height) return fail(MIRT_E_ARG, "null / empty argument");
+  if (write_bmp(path, rgb, width, height) != 0) return fail(MIRT_E_IO, std::string("could not write ") + path);
+  return MIRT_OK;
+}
+
+int mirt_bvh_build_host(const float *tri_pos, uint32_t n_tris, uint32_t leaf_size, uint32_t counts[4],
+                        uint32_t *nodes2_out, uint32_t *flat_to_orig, uint32_t *nodes4_out) {
+  if (!tri_pos || !counts || n_tris == 0) return fail(MIRT_E_ARG, "null / empty argument");
+  HostBVH b;
+  try {
+    build_reference_bvh2(tri_pos, n_tris, leaf_size, b);
+    collapse_to_wide(b);
+  } catch (const std::exception &ex) {
+    return fail(MIRT_E_LIMIT, ex.what());
+  }
+  counts[0] = (uint32_t) b.nodes2.size();
+  counts[1] = b.depth2;
+  counts[2] = (uint32_t) b.nodes4.size();
+  counts[3] = b.depth4;
+  if (nodes2_out) memcpy(nodes2_out, b.nodes2.data(), b.nodes2.size() * sizeof(Node2));
+  if (flat_to_orig) memcpy(flat_to_orig, b.flat_to_orig.data(), b.flat_to_orig.size() * 4);
+  if (nodes4_out) memcpy(nodes4_out, b.nodes4.data(), b.nodes4.size() * sizeof(Node4));
+  return MIRT_OK;
+}
+
+int mirt_tonemap_host(const float *rgb_in, uint32_t n_pixels, int32_t *rgb_out) {
+  if (!rgb_in || !rgb_out) return fail(MIRT_E_ARG, "null argument");
+  static float table[256];
+  static bool have = false;
+  if (!have) {
+    build_tonemap_table(table);
+    have = true;
+  }
+  for (size_t i = 0; i < (size_t) n_pixels * 3; i++) rgb_out[i] = tonemap_channel_table(table, rgb_in[i]);
+  return MIRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,251 @@
+// See host_bvh.hpp.  Compiled without FMA contraction: every float here must round as the reference's g++ build does.
+#include "host_bvh.hpp"
+
+#include <cmath>
+#include <limits>
+#include <stdexcept>
+
+namespace mirt {
+namespace {
+
+// util/misc.cuh:28-29 on the g++ path: maxf = std::max, minf = std::min (argument order matters for NaN)
+inline float maxf(float a, float b) { return (a < b) ? b : a; }
+inline float minf(float a, float b) { return (b < a) ? b : a; }
+
+struct Box {
+  float lo[3], hi[3];
+};
+
+struct Builder {
+  const float *pos;
+  uint32_t max_leaf;
+  std::vector<Box> pbox;                // per input triangle (primitives.cuh:170-175)
+  std::vector<float> pcent;             // centroid per triangle x3 (bbox.cuh:48-50)
+  std::vector<uint32_t> order;          // plays the role of BVHAccel::primitives (bvh.cuh:172)
+
+  struct TNode {
+    Box bb;
+    int32_t l = -1, r = -1;
+    uint32_t start = 0, end = 0;
+  };
+  std::vector<TNode> tree;
+
+  void prepare(uint32_t n) {
+    pbox.resize(n);
+    pcent.resize(3 * (size_t) n);
+    order.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+      const float *p = pos + 9 * (size_t) i;
+      Box b;
+      for (int a = 0; a < 3; a++) {
+        b.lo[a] = p[a];
+        b.hi[a] = p[a];                                 // BBox(p1)
+      }
+      for (int v = 1; v < 3; v++)
+        for (int a = 0; a < 3; a++) {                    // expand(p2), expand(p3)   bbox.cuh:38-46
+          b.lo[a] = minf(b.lo[a], p[3 * v + a]);
+          b.hi[a] = maxf(b.hi[a], p[3 * v + a]);
+        }
+      pbox[i] = b;
+      const float rc = (float) (1.0 / (double) 2.0f);    // Vector3f::operator/(float)  Vector3f.cuh:106-109
+      for (int a = 0; a < 3; a++) pcent[3 * (size_t) i + a] = rc * (b.lo[a] + b.hi[a]);
+      order[i] = i;
+    }
+  }
+
+  int32_t construct(uint32_t start, uint32_t end) {      // bvh.cuh:187-225
+    Box bb;
+    for (int a = 0; a < 3; a++) {
+      bb.lo[a] = std::numeric_limits<float>::infinity();
+      bb.hi[a] = -std::numeric_limits<float>::infinity();
+    }
+    for (uint32_t p = start; p < end; p++) {
+      const Box &b = pbox[order[p]];
+      for (int a = 0; a < 3; a++) {
+        bb.lo[a] = minf(bb.lo[a], b.lo[a]);
+        bb.hi[a] = maxf(bb.hi[a], b.hi[a]);
+      }
+    }
+    int32_t id = (int32_t) tree.size();
+    tree.emplace_back();
+    tree[id].bb = bb;
+    if ((int64_t) end - (int64_t) start <= (int64_t) max_leaf) {
+      tree[id].start = start;
+      tree[id].end = end;
+      return id;
+    }
+    float ext[3] = {bb.hi[0] - bb.lo[0], bb.hi[1] - bb.lo[1], bb.hi[2] - bb.lo[2]};
+    int axis = 0;                                        // std::max_element: first maximum under operator<
+    for (int a = 1; a < 3; a++)
+      if (ext[axis] < ext[a]) axis = a;
+    float c[3] = {0.f, 0.f, 0.f};
+    for (uint32_t p = start; p < end; p++)
+      for (int a = 0; a < 3; a++) c[a] += pcent[3 * (size_t) order[p] + a];
+    const float rc = (float) (1. / (double) (float) (end - start));   // operator/=  Vector3f.cuh:133-135
+    const float cax = c[axis] * rc;
+    auto pred = [&](uint32_t slot) { return pcent[3 * (size_t) order[slot] + axis] < cax; };
+    // libstdc++ std::partition for bidirectional iterators (bits/stl_algo.h, __partition)
+    uint32_t first = start, last = end;
+    for (;;) {
+      bool done = false;
+      for (;;) {
+        if (first == last) { done = true; break; }
+        if (pred(first)) ++first; else break;
+      }
+      if (done) break;
+      --last;
+      for (;;) {
+        if (first == last) { done = true; break; }
+        if (!pred(last)) --last; else break;
+      }
+      if (done) break;
+      std::swap(order[first], order[last]);
+      ++first;
+    }
+    const uint32_t middle = first;
+    if (middle == start || middle == end) {              // one-sided: leaf with all of them (bvh.cuh:216-220)
+      tree[id].start = start;
+      tree[id].end = end;
+      return id;
+    }
+    int32_t l = construct(start, middle);
+    int32_t r = construct(middle, end);
+    tree[id].l = l;
+    tree[id].r = r;
+    return id;
+  }
+
+  uint32_t depth_of(int32_t id, uint32_t d) const {      // bvh.cuh:297-300
+    if (tree[id].l < 0) return d;
+    uint32_t a = depth_of(tree[id].l, d + 1), b = depth_of(tree[id].r, d + 1);
+    return a < b ? b : a;
+  }
+
+  void flatten(int32_t id, HostBVH &out, uint32_t &prim_start) {   // bvh.cuh:272-290
+    uint32_t n_idx = (uint32_t) out.nodes2.size();
+    out.nodes2.emplace_back();
+    for (int a = 0; a < 3; a++) {
+      out.nodes2[n_idx].minp[a] = tree[id].bb.lo[a];
+      out.nodes2[n_idx].maxp[a] = tree[id].bb.hi[a];
+    }
+    if (tree[id].l < 0) {
+      out.nodes2[n_idx].w0 = 0x80000000u | (tree[id].end - tree[id].start);
+      out.nodes2[n_idx].w1 = prim_start;
+      for (uint32_t p = tree[id].start; p < tree[id].end; p++) out.flat_to_orig[prim_start++] = order[p];
+    } else {
+      out.nodes2[n_idx].w1 = (uint32_t) out.nodes2.size();          // idx_right = ++node_start
+      flatten(tree[id].r, out, prim_start);
+      out.nodes2[n_idx].w0 = (uint32_t) out.nodes2.size();          // idx_left
+      flatten(tree[id].l, out, prim_start);
+    }
+  }
+};
+
+inline float half_area(const Node2 &n) {
+  float dx = n.maxp[0] - n.minp[0], dy = n.maxp[1] - n.minp[1], dz = n.maxp[2] - n.minp[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+
+struct Collapser {
+  HostBVH &b;
+  uint32_t max_depth = 0;
+  explicit Collapser(HostBVH &bvh) : b(bvh) {}
+
+  static void set_child(Node4 &n, int k, const Node2 &box, uint32_t ref) {
+    n.lox[k] = box.minp[0]; n.loy[k] = box.minp[1]; n.loz[k] = box.minp[2];
+    n.hix[k] = box.maxp[0]; n.hiy[k] = box.maxp[1]; n.hiz[k] = box.maxp[2];
+    n.child[k] = ref;
+  }
+  static void clear(Node4 &n) {
+    for (int k = 0; k < 4; k++) {
+      n.lox[k] = n.loy[k] = n.loz[k] = std::numeric_limits<float>::infinity();
+      n.hix[k] = n.hiy[k] = n.hiz[k] = -std::numeric_limits<float>::infinity();
+      n.child[k] = CHILD_EMPTY;
+      n.pad[k] = 0;
+    }
+  }
+  static uint32_t leaf_ref(uint32_t start, uint32_t count) {
+    return CHILD_LEAF | (count << LEAF_COUNT_SHIFT) | start;
+  }
+
+  uint32_t child_ref(uint32_t n2, uint32_t depth) {
+    const Node2 &n = b.nodes2[n2];
+    if (n.w0 & 0x80000000u) {
+      uint32_t count = n.w0 & 0x7fffffffu;
+      if (count <= LEAF_MAX) return leaf_ref(n.w1, count);
+      // A reference leaf can hold any number of primitives (one-sided partitions, bvh.cuh:216-220).  It stays ONE leaf
+      // (one box test, all primitives tested in order, as the reference does): count field 0 + index into `big`.
+      b.big.push_back(n.w1);
+      b.big.push_back(count);
+      return leaf_ref((uint32_t) (b.big.size() / 2 - 1), 0);
+    }
+    return build(n2, depth + 1);
+  }
+
+  uint32_t build(uint32_t n2, uint32_t depth) {
+    uint32_t id = (uint32_t) b.nodes4.size();
+    b.nodes4.emplace_back();
+    clear(b.nodes4[id]);
+    if (depth > max_depth) max_depth = depth;
+    const Node2 &root = b.nodes2[n2];
+    uint32_t kids[4];
+    int nk = 0;
+    if (root.w0 & 0x80000000u) {
+      kids[nk++] = n2;                                   // a scene that is one leaf
+    } else {
+      kids[nk++] = root.w1;                              // right first: the reference pops it first (bvh.cuh:100-102)
+      kids[nk++] = root.w0;
+      while (nk < 4) {
+        int best = -1;
+        float best_a = -1.f;
+        for (int k = 0; k < nk; k++) {
+          const Node2 &c = b.nodes2[kids[k]];
+          if (c.w0 & 0x80000000u) continue;
+          float a = half_area(c);
+          if (!(a <= best_a)) { best_a = a; best = k; }
+        }
+        if (best < 0) break;
+        const Node2 &c = b.nodes2[kids[best]];
+        for (int k = nk; k > best + 1; k--) kids[k] = kids[k - 1];
+        kids[best] = c.w1;
+        kids[best + 1] = c.w0;
+        nk++;
+      }
+    }
+    for (int k = 0; k < nk; k++) {
+      uint32_t ref = child_ref(kids[k], depth);
+      set_child(b.nodes4[id], k, b.nodes2[kids[k]], ref);   // (re-index: nodes4 may have been reallocated)
+    }
+    return id;
+  }
+};
+
+}  // namespace
+
+void build_reference_bvh2(const float *tri_pos, uint32_t n, uint32_t max_leaf_size, HostBVH &out) {
+  if (n == 0) throw std::runtime_error("scene has no triangles");
+  if (n >= (1u << LEAF_COUNT_SHIFT)) throw std::runtime_error("more than 2^27-1 triangles");
+  Builder bd;
+  bd.pos = tri_pos;
+  bd.max_leaf = max_leaf_size;
+  bd.prepare(n);
+  bd.tree.reserve((size_t) n);
+  int32_t root = bd.construct(0, n);
+  out.nodes2.clear();
+  out.nodes2.reserve(bd.tree.size());
+  out.flat_to_orig.assign(n, 0);
+  uint32_t prim_start = 0;
+  bd.flatten(root, out, prim_start);
+  out.depth2 = bd.depth_of(root, 0);
+}
+
+void collapse_to_wide(HostBVH &bvh) {
+  bvh.nodes4.clear();
+  bvh.big.clear();
+  bvh.nodes4.reserve(bvh.nodes2.size() / 2 + 4);
+  Collapser c(bvh);
+  c.build(0, 0);
+  bvh.depth4 = c.max_depth;
+}
+
+}  // namespace mirt

@@ -1,0 +1,52 @@
+// Host-side acceleration-structure build for libmirt (product code; independent of oracle/).
+//
+// Two stages:
+//  1. build_reference_bvh2(): reproduces, bit for bit, the BVH the reference builds on the host
+//     (bvh/bvh.cuh:187-225 construct_bvh, :272-290 flatten): mean-centroid split on the longest axis,
+//     libstdc++'s bidirectional std::partition, pre-order flatten with the RIGHT child first.  Its flat
+//     primitive order is what "hit index" means in every parity test, so it is not negotiable.
+//  2. collapse_to_wide(): folds that binary tree into 4-wide, 128-byte, SoA nodes for the HIP kernels,
+//     keeping the children of every wide node in the reference's DFS order so the `traversal = 1` mode can
+//     visit leaves exactly as the reference does.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace mirt {
+
+struct Node2 {            // = BVHNodeOpt (bvh/bvh.cuh:12-30), 32 bytes
+  float minp[3];
+  float maxp[3];
+  uint32_t w0;            // inner: idx_left   | leaf: count | 0x80000000
+  uint32_t w1;            // inner: idx_right  | leaf: idx_start
+};
+static_assert(sizeof(Node2) == 32, "Node2 layout");
+
+constexpr uint32_t WIDE = 4;
+constexpr uint32_t CHILD_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t CHILD_LEAF = 0x80000000u;
+constexpr uint32_t LEAF_MAX = 15;            // primitives per inline leaf reference; larger leaves: count field 0, low bits index HostBVH::big
+constexpr uint32_t LEAF_COUNT_SHIFT = 27;    // ref = LEAF | count << 27 | start  (start < 2^27)
+
+struct alignas(128) Node4 {                  // 128 bytes, one or two cache lines, SoA over the four children
+  float lox[4], loy[4], loz[4];
+  float hix[4], hiy[4], hiz[4];
+  uint32_t child[4];                         // CHILD_EMPTY | inner node index | leaf reference
+  uint32_t pad[4];
+};
+static_assert(sizeof(Node4) == 128, "Node4 layout");
+
+struct HostBVH {
+  std::vector<Node2> nodes2;
+  std::vector<uint32_t> flat_to_orig;        // flat slot -> caller's triangle index
+  uint32_t depth2 = 0;
+  std::vector<Node4> nodes4;
+  std::vector<uint32_t> big;                 // (start, count) pairs of reference leaves with more than LEAF_MAX primitives
+  uint32_t depth4 = 0;
+};
+
+// tri_pos: n x 9 floats.  Throws std::runtime_error on limits.
+void build_reference_bvh2(const float *tri_pos, uint32_t n, uint32_t max_leaf_size, HostBVH &out);
+void collapse_to_wide(HostBVH &bvh);
+
+}  // namespace mirt

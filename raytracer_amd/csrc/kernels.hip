@@ -1,0 +1,738 @@
+// gfx950 kernels of the wavefront path tracer (see DESIGN.md for the data layout and the roofline of each).
+//
+//   k_init            per-slot path state, reference seed procedure (renderer.cuh:50-51)
+//   k_logic           fold shadow results -> finish sample -> shade the hit (raytracer.cuh:30-126) -> emit the next
+//                     extension ray and the shadow rays into compacted queues (wave64 ballot / mbcnt)
+//   k_trace4<ANY,..>  persistent-thread traversal of the 4-wide BVH (LDS stack, dynamic ray fetch)
+//   k_trace2<ANY>     the reference's own BVH2 walk (bvh.cuh:49-107), used for the `traversal = 2` cross-check and
+//                     for the few rays whose slab / hit arithmetic goes non-finite (results then depend on visit order)
+//   k_tonemap         film: divide + threshold-table tonemap (util/image.cuh:36-48)
+//
+// Built with -ffp-contract=off: the reference's g++ build never fuses a*b+c.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "shade.hpp"
+
+namespace mirt {
+
+// ============================================================================================ helpers
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {       // set bits of `mask` below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+}
+
+// Wave-aggregated reservation of `n_each` consecutive queue entries for every lane that calls it (the calling lanes are
+// the active lanes of a divergent branch): one atomic per wave.
+__device__ __forceinline__ uint32_t wave_reserve(uint32_t *counter, uint32_t n_each) {
+  const uint64_t m = __ballot(1);
+  const uint32_t rank = lane_rank(m);
+  uint32_t base = 0;
+  if (rank == 0) base = atomicAdd(counter, (uint32_t) __popcll(m) * n_each);
+  base = __builtin_amdgcn_readfirstlane(base);
+  return base + rank * n_each;
+}
+
+__device__ __forceinline__ void slot_to_pixel(const RenderArgs &a, uint32_t slot, uint32_t &px, uint32_t &py, bool &valid) {
+  // slots are 8x8 pixel tiles (one wave = one tile); tiles are dealt round-robin over the processes of a tile partition
+  const uint32_t tile_local = slot >> 6, lane = slot & 63;
+  const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
+  const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  px = tx * 8 + (lane & 7);
+  py = ty * 8 + (lane >> 3);
+  valid = (ty < a.tiles_y) && px < a.width && py < a.height;
+}
+
+// ============================================================================================ k_init
+__global__ void k_init(RenderArgs a) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.n_slots) return;
+  uint32_t px, py;
+  bool valid;
+  slot_to_pixel(a, s, px, py, valid);
+  uint4 st = make_uint4(0, 1, 0, 0);
+  if (!valid) {
+    st.z = F_DONE;
+  } else if (a.rng_mode == 0) {
+    Rng r;
+    r.mode = 0; r.key = 0; r.sample = 0;
+    r.state = (0x42ffffffU & (py * a.width + px)) ^ a.seed;          // renderer.cuh:50
+    for (int k = 0; k < 10; k++) rng_next(r);                        // renderer.cuh:51
+    st.x = r.state;
+  }
+  a.st[s] = st;
+  a.mask[s] = make_float4(1, 1, 1, 0);
+  a.total[s] = make_float4(0, 0, 0, 0);
+  a.accum[s] = make_float4(0, 0, 0, 0);
+}
+
+// ============================================================================================ k_logic
+struct PathCtx {
+  Rng rng;
+  uint32_t i;          // 1-based index of the sample being accumulated (raytracer.cuh:97)
+  uint32_t flags;
+  uint32_t depth;
+};
+
+__device__ __forceinline__ void emit_extension(const RenderArgs &a, uint32_t s, const DRay &r, bool primary) {
+  a.ray_o[s] = make_float4(r.o.x, r.o.y, r.o.z, r.min_t);
+  a.ray_d[s] = make_float4(r.d_arg.x, r.d_arg.y, r.d_arg.z, r.max_t);
+  if (primary) {
+    uint32_t pos = wave_reserve(a.qcount + QC_EXT_FRONT, 1);         // coherent camera rays: front of the queue
+    a.ext_queue[pos] = s;
+  } else {
+    uint32_t pos = wave_reserve(a.qcount + QC_EXT_BACK, 1);          // bounced rays: back of the same array
+    a.ext_queue[a.n_slots - 1 - pos] = s;
+  }
+}
+
+// raytracer.cuh:100-107: jittered film point -> camera ray.  `sample_index` only matters in counter mode.
+__device__ __forceinline__ void generate_camera_ray(const RenderArgs &a, uint32_t s, uint32_t px, uint32_t py,
+                                                    PathCtx &c, uint32_t sample_number) {
+  if (c.rng.mode == 1) {
+    c.rng.state = 0;
+    c.rng.sample = a.sample_begin + sample_number - 1;
+  }
+  float gx = rng_next(c.rng);
+  float gy = rng_next(c.rng);
+  float fx = (float) px + gx, fy = (float) py + gy;
+  DRay r = camera_generate_ray(a.cam, fx / (float) a.width, fy / (float) a.height, c.rng);
+  emit_extension(a, s, r, true);
+  c.depth = 0;
+  c.flags |= F_HAS_RAY;
+}
+
+__device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s, const uint4 st, uint32_t &n_closest,
+                                           uint32_t &n_shadow_rays, uint32_t &n_paths) {
+  uint32_t px, py;
+  bool valid;
+  slot_to_pixel(a, s, px, py, valid);
+
+  PathCtx c;
+  c.rng.mode = a.rng_mode;
+  c.rng.state = st.x;
+  c.rng.key = (a.rng_mode == 1) ? ctr_key(py * a.width + px, a.seed) : 0;
+  c.i = st.y;
+  c.flags = st.z & 0xFF;
+  c.depth = st.w;
+  // counter mode: the path in flight belongs to sample i, or to i + 1 when it was started ahead of the finalisation
+  c.rng.sample = a.sample_begin + c.i + ((c.flags & F_AHEAD) ? 1u : 0u) - 1u;
+  uint32_t n_shadow = (st.z >> 8) & 0xFFFF;
+
+  float4 tot4 = a.total[s];
+  V3 total = mk(tot4.x, tot4.y, tot4.z);
+  float s1 = tot4.w;
+
+  // ---- 1. fold the shadow rays emitted at the previous hit (raytracer.cuh:43-47, :68)
+  if (n_shadow) {
+    float4 dm = a.dmask[s];
+    V3 color = mk(0, 0, 0);
+    for (uint32_t k = 0; k < n_shadow; k++) {
+      size_t e = (size_t) k * a.n_slots + s;
+      if (a.sh_occ[e] == 0) {
+        float4 cc = a.sh_c[e];
+        color = vadd(color, mk(cc.x, cc.y, cc.z));
+      }
+    }
+    total = vadd(total, vmul(mk(dm.x, dm.y, dm.z), color));
+    n_shadow = 0;
+  }
+
+  float4 acc4 = a.accum[s];
+  bool finished = false;
+  float divisor = 0.f;
+
+  // finish sample c.i: raytracer.cuh:111-122
+  auto finalize = [&]() {
+    acc4.x += total.x; acc4.y += total.y; acc4.z += total.z;
+    float illum = villum(total);
+    s1 += illum;
+    total = mk(0, 0, 0);
+    bool stop = false;
+    if (a.adaptive && (c.i % a.batch) == 0) {
+      float variance = (float) (((double) s1 - ((double) s1 * (double) s1) / (double) (int) c.i) / (double) ((int) c.i - 1));
+      float mean = s1 / (float) (int) c.i;
+      stop = (1.96 * (double) sqrtf(variance / (float) (int) c.i)) <= (double) (a.tol * mean);
+    }
+    if (stop) {
+      finished = true;
+      divisor = (float) ((int) c.i - 1);          // raytracer.cuh:124 after `break`: i was not incremented
+    } else {
+      c.i++;
+      if (c.i > a.spp) {
+        finished = true;
+        divisor = (float) ((int) c.i - 1);
+      }
+    }
+  };
+
+  // ---- 2. a sample that ended at the previous hit but still waited for its shadow rays
+  if (c.flags & F_PENDING) {
+    c.flags &= ~F_PENDING;
+    finalize();
+    c.flags &= ~F_AHEAD;
+  }
+
+  if (!finished) {
+    if (!(c.flags & F_HAS_RAY)) {
+      // ---- first sample of the pixel
+      n_paths++;
+      n_closest++;
+      a.mask[s] = make_float4(1, 1, 1, 0);
+      generate_camera_ray(a, s, px, py, c, c.i);
+    } else {
+      // ---- 3. the extension ray of this path was traced: shade (estimate_global_lighting body, raytracer.cuh:60-88)
+      float4 h = a.hit[s];
+      const int32_t prim = (int32_t) f2u(h.w);
+      float4 m4 = a.mask[s];
+      V3 mask = mk(m4.x, m4.y, m4.z);
+      bool path_ends = false;
+      DRay next;
+      if (prim < 0) {
+        path_ends = true;                                   // miss: break (raytracer.cuh:62)
+      } else {
+        const float4 ro = a.ray_o[s], rd = a.ray_d[s];
+        const V3 origin = mk(ro.x, ro.y, ro.z);
+        const V3 direction = vunit(mk(rd.x, rd.y, rd.z));   // Ray::direction (ray.cuh:20)
+        const float4 n0 = a.tri_nrm[3 * (size_t) prim], n1 = a.tri_nrm[3 * (size_t) prim + 1],
+                     n2 = a.tri_nrm[3 * (size_t) prim + 2];
+        const uint32_t mat = f2u(n2.y);
+        const float by = h.y, bz = h.z;
+        const float bx = 1 - by - bz;                       // primitives.cuh:147
+        DIsect is;
+        is.normal = vadd(vadd(vlscale(bx, mk(n0.x, n0.y, n0.z)), vlscale(by, mk(n0.w, n1.x, n1.y))),
+                         vlscale(bz, mk(n1.z, n1.w, n2.x)));           // primitives.cuh:156
+        isect_compute(is, origin, direction, h.x);
+        DBsdf bsdf;
+        {
+          const float *mp = a.mats + 9 * (size_t) mat;
+          bsdf.type = (int32_t) f2u(mp[0]);
+#pragma unroll
+          for (int k = 0; k < 8; k++) bsdf.p[k] = mp[1 + k];
+        }
+        if (bsdf.type == BSDF_EMISSION) total = vadd(total, vmul(mask, mk(bsdf.p[0], bsdf.p[1], bsdf.p[2])));
+        else total = vadd(total, vmul(mask, mk(0, 0, 0)));  // raytracer.cuh:65 (keeps inf/NaN * 0 semantics)
+
+        if (!bsdf_is_delta(bsdf.type)) {
+          // estimate_direct_lighting (raytracer.cuh:30-51): one shadow ray per light sample, traced by k_trace*<ANY>
+          const V3 bump = vscale(is.normal, 0.001f);
+          const V3 so = vadd(is.hit_point, bump);
+          uint32_t k = 0;
+          for (uint32_t li = 0; li < a.n_lights; li++) {
+            DLight L;
+            {
+              const float *lp = a.lights + 17 * (size_t) li;
+              L.type = (int32_t) f2u(lp[0]);
+#pragma unroll
+              for (int q = 0; q < 16; q++) L.p[q] = lp[1 + q];
+            }
+            for (uint32_t j = 0; j < a.spl; j++, k++) {
+              V3 to_light;
+              float dist, pdf;
+              V3 Lr = light_sample(L, so, to_light, dist, pdf, c.rng);
+              V3 f = bsdf_f(bsdf, is.o_out, mmulv(is.w2o, to_light));
+              V3 sdir = vunit(to_light);                                // shadow_ray.direction
+              float cosv = smax(vdot(is.normal, vunit(sdir)), 0.f);     // raytracer.cuh:45
+              V3 contrib = vdiv(vdiv(vscale(vmul(f, Lr), cosv), pdf), (float) a.spl);
+              size_t e = (size_t) k * a.n_slots + s;
+              a.sh_o[e] = make_float4(so.x, so.y, so.z, MIRT_EPS);
+              a.sh_d[e] = make_float4(to_light.x, to_light.y, to_light.z, dist - MIRT_EPS);
+              a.sh_c[e] = make_float4(contrib.x, contrib.y, contrib.z, 0);
+              uint32_t pos = wave_reserve(a.qcount + QC_SHADOW, 1);
+              a.sh_queue[pos] = (uint32_t) e;
+            }
+          }
+          n_shadow = k;
+          n_shadow_rays += k;
+          a.dmask[s] = make_float4(mask.x, mask.y, mask.z, 0);
+        }
+
+        float cpdf = smax(mask.x, smax(mask.y, mask.z));                // raytracer.cuh:71
+        if (!(rng_next(c.rng) < cpdf)) {
+          path_ends = true;                                             // :72-74
+        } else {
+          float pdf;
+          V3 bmask;
+          V3 o_in = bsdf_sample(bsdf, is.o_out, bmask, pdf, c.rng, a.glass_int_abs != 0);
+          if (pdf == 0) {
+            path_ends = true;                                           // :79
+          } else {
+            V3 bump = vscale(is.normal, 0.001f);
+            bump = o_in.z > 0 ? bump : vneg(bump);
+            next.o = vadd(is.hit_point, bump);
+            next.d_arg = mmulv(is.o2w, o_in);
+            next.min_t = MIRT_EPS;
+            next.max_t = MIRT_INF;
+            mask = vdiv(vdiv(vscale(vmul(mask, bmask), o_in.z), pdf), smin(cpdf, 1.f));   // :85
+            c.depth++;
+            if (c.depth > a.max_depth) path_ends = true;                // loop bound `i <= max_ray_depth` (:60)
+          }
+        }
+      }
+
+      if (!path_ends) {
+        a.mask[s] = make_float4(mask.x, mask.y, mask.z, 0);
+        emit_extension(a, s, next, false);
+        n_closest++;
+      } else {
+        c.flags &= ~F_HAS_RAY;
+        if (n_shadow > 0) {
+          // the sample is complete except for its last shadow rays: finish it next iteration, and meanwhile already
+          // start the following sample (its camera ray is traced alongside those shadow rays)
+          c.flags |= F_PENDING;
+          if (c.i + 1 <= a.spp) {
+            c.flags |= F_AHEAD;
+            n_paths++;
+            n_closest++;
+            a.mask[s] = make_float4(1, 1, 1, 0);
+            generate_camera_ray(a, s, px, py, c, c.i + 1);
+          }
+        } else {
+          finalize();
+          if (!finished) {
+            n_paths++;
+            n_closest++;
+            a.mask[s] = make_float4(1, 1, 1, 0);
+            generate_camera_ray(a, s, px, py, c, c.i);
+          }
+        }
+      }
+    }
+  }
+
+  if (finished) {
+    c.flags = F_DONE;
+    n_shadow = 0;
+    a.out_accum[(size_t) py * a.width + px] = make_float4(acc4.x, acc4.y, acc4.z, divisor);
+  } else {
+    uint64_t m = __ballot(1);
+    if (lane_rank(m) == 0) atomicAdd(a.qcount + QC_ACTIVE, (uint32_t) __popcll(m));
+  }
+  a.total[s] = make_float4(total.x, total.y, total.z, s1);
+  a.accum[s] = acc4;
+  a.st[s] = make_uint4(c.rng.state, c.i, c.flags | (n_shadow << 8), c.depth);
+
+}
+
+__global__ void __launch_bounds__(256) k_logic(RenderArgs a) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t n_closest = 0, n_shadow_rays = 0, n_paths = 0;
+  if (s < a.n_slots) {
+    const uint4 st = a.st[s];
+    if (!(st.z & F_DONE)) logic_slot(a, s, st, n_closest, n_shadow_rays, n_paths);
+  }
+  // ray statistics: every lane of the wave takes part in the reduction (finished slots contribute zeros); one atomic per
+  // wave and counter
+  {
+    uint32_t v0 = n_closest, v1 = n_shadow_rays, v2 = n_paths;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      v0 += __shfl_xor(v0, o);
+      v1 += __shfl_xor(v1, o);
+      v2 += __shfl_xor(v2, o);
+    }
+    const uint64_t m = __ballot(1);
+    if (lane_rank(m) == 0) {
+      if (v0) atomicAdd((unsigned long long *) a.ray_stats + 0, (unsigned long long) v0);
+      if (v1) atomicAdd((unsigned long long *) a.ray_stats + 1, (unsigned long long) v1);
+      if (v2) atomicAdd((unsigned long long *) a.ray_stats + 2, (unsigned long long) v2);
+    }
+  }
+}
+
+// ============================================================================================ traversal
+struct LaneRay {
+  V3 o, d, inv;          // origin, normalised direction (M-T), reciprocal of the ctor argument (slab test)
+  float min_t, best_t;
+  float b1, b2;
+  int32_t best_idx;
+  uint32_t id;
+};
+
+__device__ __forceinline__ bool finite3(V3 v) {
+  return (fabsf(v.x) < MIRT_INF) && (fabsf(v.y) < MIRT_INF) && (fabsf(v.z) < MIRT_INF);
+}
+
+__device__ __forceinline__ void load_ray(const TraceArgs &a, uint32_t id, LaneRay &r) {
+  const float4 ro = a.ray_o[id], rd = a.ray_d[id];
+  r.o = mk(ro.x, ro.y, ro.z);
+  const V3 d_arg = mk(rd.x, rd.y, rd.z);
+  r.d = vunit(d_arg);                 // ray.cuh:20
+  r.inv = vrcp(d_arg);                // ray.cuh:21 (of the argument: SURVEY Q1)
+  r.min_t = ro.w;
+  r.best_t = rd.w;
+  r.b1 = 0; r.b2 = 0;
+  r.best_idx = -1;
+  r.id = id;
+}
+
+// Moeller-Trumbore exactly as primitives.cuh:137-158 evaluates it (e1, e2 are stored: same subtraction, same bits).
+// Returns the reference's accept decision against `max_t`.
+__device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const LaneRay &r, float max_t, float &t,
+                                         float &by, float &bz) {
+  const float4 q0 = tris[3 * (size_t) idx], q1 = tris[3 * (size_t) idx + 1], q2 = tris[3 * (size_t) idx + 2];
+  const V3 p1 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
+  const V3 s = vsub(r.o, p1);
+  const V3 s1 = vcross(r.d, e2);
+  const V3 s2 = vcross(s, e1);
+  const float rc = 1.0f / vdot(s1, e1);
+  t = rc * vdot(s2, e2);
+  by = rc * vdot(s1, s);
+  bz = rc * vdot(s2, r.d);
+  const float bx = 1 - by - bz;
+  return !(t < 0 || t <= r.min_t || t > max_t || bx < 0 || by < 0 || bz < 0);
+}
+
+// -------------------------------------------------------------------------------------------- k_trace2 (reference walk)
+// bbox.cuh:67-79 with std::max / std::min argument order
+__device__ __forceinline__ bool slab_exact(const float *lo, const float *hi, const LaneRay &r, float max_t) {
+  float tmin = 0.0f, tmax = max_t;
+  const float o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {r.inv.x, r.inv.y, r.inv.z};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float t1 = (lo[d] - o[d]) * inv[d];
+    float t2 = (hi[d] - o[d]) * inv[d];
+    tmin = smin(smax(t1, tmin), smax(t2, tmin));
+    tmax = smax(smin(t1, tmax), smin(t2, tmax));
+  }
+  return tmin <= tmax && tmax > r.min_t;
+}
+
+template<bool ANY>
+__global__ void __launch_bounds__(256) k_trace2(TraceArgs a) {
+  const uint32_t total = a.redo ? *a.redo_count : (a.qcount[a.qc_front] + (a.qc_back >= 0 ? a.qcount[a.qc_back] : 0));
+  const uint32_t nA = a.redo ? total : a.qcount[a.qc_front];
+  if (a.redo && a.redo_stat && total && blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(a.redo_stat, (unsigned long long) total);
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += gridDim.x * blockDim.x) {
+    uint32_t id = a.redo ? a.redo_queue[w] : (w < nA ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)]);
+    LaneRay r;
+    load_ray(a, id, r);
+    uint32_t stack[BVH2_STACK];
+    uint32_t sp = 0;
+    stack[sp++] = 0;
+    bool found = false;
+    while (sp) {
+      const float4 *np = a.nodes2 + 2 * (size_t) stack[--sp];
+      const float4 n0 = np[0], n1 = np[1];
+      const float lo[3] = {n0.x, n0.y, n0.z}, hi[3] = {n0.w, n1.x, n1.y};
+      const uint32_t w0 = f2u(n1.z), w1 = f2u(n1.w);
+      if (!slab_exact(lo, hi, r, r.best_t)) continue;
+      if (w0 & 0x80000000u) {
+        const uint32_t cnt = w0 & 0x7fffffffu;
+        for (uint32_t i = w1; i < w1 + cnt; i++) {
+          float t, by, bz;
+          if (tri_test(a.tris, i, r, r.best_t, t, by, bz)) {
+            r.best_t = t; r.b1 = by; r.b2 = bz; r.best_idx = (int32_t) i;
+            if (ANY) { found = true; break; }
+          }
+        }
+        if (ANY && found) break;
+      } else if (sp + 2 <= BVH2_STACK) {
+        stack[sp++] = w0;
+        stack[sp++] = w1;
+      } else {
+        atomicOr(a.error_flag, 1u);
+      }
+    }
+    if (ANY) {
+      a.occ[id] = found ? 1u : 0u;
+      if (a.any_t) a.any_t[id] = r.best_t;
+    } else {
+      a.hit[id] = make_float4(r.best_t, r.b1, r.b2, u2f((uint32_t) r.best_idx));
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------- k_trace4 (wide BVH)
+// MODE 0: children sorted near-to-far (ordered traversal; equal-t hits resolved by the tie rule "larger flat index wins",
+//         which is what the reference's fixed visiting order produces);  MODE 1: children in the reference's DFS order.
+template<bool ANY, int MODE>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
+  extern __shared__ uint2 lds_stack[];                    // [LDS_STACK][TRACE_BLOCK]
+  const uint32_t tid = threadIdx.x;
+  const uint32_t gtid = blockIdx.x * TRACE_BLOCK + tid;
+  const uint32_t nthreads = gridDim.x * TRACE_BLOCK;
+  const uint32_t nA = a.qcount[a.qc_front];
+  const uint32_t total = nA + (a.qc_back >= 0 ? a.qcount[a.qc_back] : 0);
+
+  LaneRay r;
+  r.id = 0; r.best_idx = -1; r.best_t = 0; r.min_t = 0; r.b1 = r.b2 = 0;
+  r.o = r.d = r.inv = mk(0, 0, 0);
+  bool active = false, exhausted = false;
+  uint32_t cur = CHILD_EMPTY;
+  int sp = 0;
+
+  auto push = [&](uint32_t ref, float tmn) {
+    if (sp < LDS_STACK) lds_stack[sp * TRACE_BLOCK + tid] = make_uint2(ref, f2u(tmn));
+    else if (sp < LDS_STACK + (int) a.ovf_depth) a.ovf[(size_t) (sp - LDS_STACK) * nthreads + gtid] = make_uint2(ref, f2u(tmn));
+    else { atomicOr(a.error_flag, 2u); return; }
+    sp++;
+  };
+  auto pop = [&]() {                                       // next node whose entry distance is still in range
+    cur = CHILD_EMPTY;
+    while (sp > 0) {
+      sp--;
+      uint2 e = (sp < LDS_STACK) ? lds_stack[sp * TRACE_BLOCK + tid] : a.ovf[(size_t) (sp - LDS_STACK) * nthreads + gtid];
+      if (ANY || u2f(e.y) <= r.best_t) { cur = e.x; break; }
+    }
+  };
+
+  while (true) {
+    // ---------------------------------------------------------------- dynamic fetch: one atomic per wave
+    if (!active && !exhausted) {
+      const uint32_t w = wave_reserve(a.work_head, 1);
+      if (w < total) {
+        const uint32_t id = (w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)];
+        load_ray(a, id, r);
+        // Slab and hit arithmetic stays finite for these rays; anything else (zero direction components -> 0 * inf,
+        // non-finite origins, NaN bounds) makes the reference's result depend on its visiting order: defer to k_trace2.
+        bool regular = finite3(r.o) && finite3(r.d) && finite3(r.inv) && (r.best_t == r.best_t) &&
+                       (r.min_t == r.min_t);
+        if (MODE == 0 && !ANY) {
+          // The reference prunes boxes with t measured along the UN-normalised ctor direction but hits with t along the
+          // normalised one (ray.cuh:19-21): unless the two agree (the integrator only makes unit directions) its result
+          // depends on the visiting order, so such rays take the reference walk too.
+          const float4 rd = a.ray_d[id];
+          const float l2 = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
+          regular = regular && (fabsf(l2 - 1.0f) < 1e-4f);
+        }
+        if (regular) {
+          active = true;
+          cur = 0;
+          sp = 0;
+        } else {
+          const uint32_t pos = wave_reserve(a.redo_count, 1);
+          a.redo_queue[pos] = id;
+        }
+      } else {
+        exhausted = true;
+      }
+    }
+    if (!__any(active)) {
+      if (__all(exhausted)) break;
+      continue;
+    }
+
+    // ---------------------------------------------------------------- inner nodes
+    while (active && cur != CHILD_EMPTY && !(cur & CHILD_LEAF)) {
+      const float4 *np = a.nodes4 + 8 * (size_t) cur;
+      const float4 LX = np[0], LY = np[1], LZ = np[2], HX = np[3], HY = np[4], HZ = np[5];
+      const float4 CHf = np[6];
+      const float lox[4] = {LX.x, LX.y, LX.z, LX.w}, loy[4] = {LY.x, LY.y, LY.z, LY.w}, loz[4] = {LZ.x, LZ.y, LZ.z, LZ.w};
+      const float hix[4] = {HX.x, HX.y, HX.z, HX.w}, hiy[4] = {HY.x, HY.y, HY.z, HY.w}, hiz[4] = {HZ.x, HZ.y, HZ.z, HZ.w};
+      uint32_t ch[4] = {f2u(CHf.x), f2u(CHf.y), f2u(CHf.z), f2u(CHf.w)};
+      float key[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        // bbox.cuh:71-75 for finite operands: the running std::max/std::min chain equals these min/max trees
+        const float t1x = (lox[c] - r.o.x) * r.inv.x, t2x = (hix[c] - r.o.x) * r.inv.x;
+        const float t1y = (loy[c] - r.o.y) * r.inv.y, t2y = (hiy[c] - r.o.y) * r.inv.y;
+        const float t1z = (loz[c] - r.o.z) * r.inv.z, t2z = (hiz[c] - r.o.z) * r.inv.z;
+        const float tmn = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
+        const float tmx = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), r.best_t));
+        const bool hit = (ch[c] != CHILD_EMPTY) && (tmn <= tmx) && (tmx > r.min_t);
+        key[c] = hit ? tmn : MIRT_INF;
+        if (!hit) ch[c] = CHILD_EMPTY;
+      }
+      if (MODE == 0 && !ANY) {
+        // 5-comparator sorting network on (key, child): nearest first
+#define MIRT_CE(i, j)                                                         \
+  {                                                                           \
+    const bool sw = key[j] < key[i];                                          \
+    const float ki = sw ? key[j] : key[i], kj = sw ? key[i] : key[j];         \
+    const uint32_t ci = sw ? ch[j] : ch[i], cj = sw ? ch[i] : ch[j];          \
+    key[i] = ki; key[j] = kj; ch[i] = ci; ch[j] = cj;                         \
+  }
+        MIRT_CE(0, 1) MIRT_CE(2, 3) MIRT_CE(0, 2) MIRT_CE(1, 3) MIRT_CE(1, 2)
+#undef MIRT_CE
+      }
+      // descend into the first surviving child, push the others so that the earlier ones pop first
+      uint32_t first = CHILD_EMPTY;
+#pragma unroll
+      for (int c = 3; c >= 0; c--) {
+        if (ch[c] != CHILD_EMPTY) {
+          bool earlier = false;
+#pragma unroll
+          for (int e = 0; e < c; e++) earlier = earlier || (ch[e] != CHILD_EMPTY);
+          if (earlier) push(ch[c], key[c]);
+          else first = ch[c];
+        }
+      }
+      if (first != CHILD_EMPTY) cur = first;
+      else pop();
+    }
+
+    // ---------------------------------------------------------------- leaf
+    if (active && cur != CHILD_EMPTY && (cur & CHILD_LEAF)) {
+      uint32_t start = cur & ((1u << LEAF_COUNT_SHIFT) - 1);
+      uint32_t cnt = (cur >> LEAF_COUNT_SHIFT) & 15u;
+      if (cnt == 0) {                                     // oversized reference leaf: (start, count) lives in a side table
+        const uint2 bl = a.big[start];
+        start = bl.x;
+        cnt = bl.y;
+      }
+      bool found = false, irregular = false;
+      for (uint32_t i = start; i < start + cnt; i++) {
+        float t, by, bz;
+        if (tri_test(a.tris, i, r, r.best_t, t, by, bz)) {
+          if (!(fabsf(t) < MIRT_INF)) { irregular = true; break; }        // accepted NaN / inf hit
+          // ordered traversal may meet equal-t hits in any order: the reference ends with the largest flat index
+          if (MODE == 0 && !ANY && t == r.best_t && (int32_t) i < r.best_idx) continue;
+          r.best_t = t; r.b1 = by; r.b2 = bz; r.best_idx = (int32_t) i;
+          if (ANY) { found = true; break; }
+        }
+      }
+      if (irregular) {
+        const uint32_t pos = wave_reserve(a.redo_count, 1);
+        a.redo_queue[pos] = r.id;
+        active = false;
+      } else if (ANY && found) {
+        a.occ[r.id] = 1u;
+        if (a.any_t) a.any_t[r.id] = r.best_t;
+        active = false;
+      } else {
+        pop();
+      }
+    }
+
+    // ---------------------------------------------------------------- ray finished
+    if (active && cur == CHILD_EMPTY) {
+      if (ANY) {
+        a.occ[r.id] = 0u;
+        if (a.any_t) a.any_t[r.id] = r.best_t;
+      } else {
+        a.hit[r.id] = make_float4(r.best_t, r.b1, r.b2, u2f((uint32_t) r.best_idx));
+      }
+      active = false;
+    }
+  }
+}
+
+// ============================================================================================ probes
+// Sample-0 camera rays with the reference seed procedure, for mirt_primary_hits.
+__global__ void k_probe_primary(RenderArgs a) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.n_slots) return;
+  uint32_t px, py;
+  bool valid;
+  slot_to_pixel(a, s, px, py, valid);
+  if (!valid) return;
+  PathCtx c;
+  c.rng.mode = a.rng_mode;
+  c.rng.state = a.st[s].x;
+  c.rng.key = (a.rng_mode == 1) ? ctr_key(py * a.width + px, a.seed) : 0;
+  c.rng.sample = 0;
+  c.i = 1; c.flags = 0; c.depth = 0;
+  generate_camera_ray(a, s, px, py, c, 1);
+}
+
+__global__ void k_gather_primary(RenderArgs a, int32_t *idx_out, uint32_t *tbits_out) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.n_slots) return;
+  uint32_t px, py;
+  bool valid;
+  slot_to_pixel(a, s, px, py, valid);
+  if (!valid) return;
+  const float4 h = a.hit[s];
+  idx_out[(size_t) py * a.width + px] = (int32_t) f2u(h.w);
+  tbits_out[(size_t) py * a.width + px] = f2u(h.x);
+}
+
+__global__ void k_iota(uint32_t *q, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) q[i] = i;
+}
+
+// ============================================================================================ film
+__global__ void k_tonemap(const float4 *accum, uint32_t n, const float *table, int32_t *rgb) {
+  __shared__ float T[256];
+  T[threadIdx.x & 255] = table[threadIdx.x & 255];
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = accum[i];
+  const float rc = 1.0f / v.w;                    // color /= i - 1  (raytracer.cuh:124; Vector3f.cuh:133-135)
+  const float c3[3] = {v.x * rc, v.y * rc, v.z * rc};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float c = c3[k];
+    int out;
+    if (c != c || c < 0.f) out = 255;             // powf of NaN / negative -> NaN -> min(1, NaN) = 1 (image.cuh:44)
+    else {
+      int lo = 0, hi = 256;
+#pragma unroll
+      for (int it = 0; it < 8; it++) {
+        const int mid = (lo + hi) >> 1;
+        if (c >= T[mid]) lo = mid; else hi = mid;
+      }
+      out = lo;
+    }
+    rgb[3 * (size_t) i + k] = out;
+  }
+}
+
+// ============================================================================================ launchers
+#define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t launch_init(const RenderArgs &a, hipStream_t st) {
+  k_init<<<(a.n_slots + 255) / 256, 256, 0, st>>>(a);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_logic(const RenderArgs &a, hipStream_t st) {
+  k_logic<<<(a.n_slots + 255) / 256, 256, 0, st>>>(a);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_probe_primary(const RenderArgs &a, hipStream_t st) {
+  k_probe_primary<<<(a.n_slots + 255) / 256, 256, 0, st>>>(a);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_gather_primary(const RenderArgs &a, int32_t *idx, uint32_t *tb, hipStream_t st) {
+  k_gather_primary<<<(a.n_slots + 255) / 256, 256, 0, st>>>(a, idx, tb);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_iota(uint32_t *q, uint32_t n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  k_iota<<<(n + 255) / 256, 256, 0, st>>>(q, n);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_tonemap(const void *accum, uint32_t n, const float *table, int32_t *rgb, hipStream_t st) {
+  k_tonemap<<<(n + 255) / 256, 256, 0, st>>>((const float4 *) accum, n, table, rgb);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+size_t trace4_lds_bytes() { return (size_t) LDS_STACK * TRACE_BLOCK * sizeof(uint2); }
+
+int trace4_blocks_per_cu() {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace4<false, 0>, TRACE_BLOCK, trace4_lds_bytes()) != hipSuccess || nb < 1)
+    nb = 2;
+  return nb;
+}
+
+// traversal: 0 ordered wide, 1 DFS-order wide, 2 reference BVH2.  `a.redo` selects the deferred-ray pass of k_trace2.
+hipError_t launch_trace(const TraceArgs &a, bool any, uint32_t traversal, uint32_t grid_blocks, hipStream_t st) {
+  if (a.redo || traversal == 2) {
+    if (any) k_trace2<true><<<grid_blocks, 256, 0, st>>>(a);
+    else k_trace2<false><<<grid_blocks, 256, 0, st>>>(a);
+  } else {
+    const size_t lds = trace4_lds_bytes();
+    if (any) {
+      // the boolean of an any-hit query does not depend on the visiting order: one instantiation serves both modes
+      k_trace4<true, 1><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+    } else if (traversal == 0) {
+      k_trace4<false, 0><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+    } else {
+      k_trace4<false, 1><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+    }
+  }
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+
+}  // namespace mirt

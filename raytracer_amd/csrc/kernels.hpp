@@ -1,0 +1,74 @@
+// Argument blocks and launch wrappers shared by kernels.hip (device) and capi.cpp (host orchestration).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "host_bvh.hpp"
+#include "shade.hpp"
+
+namespace mirt {
+
+constexpr int TRACE_BLOCK = 256;
+constexpr int LDS_STACK = 12;        // traversal-stack entries per lane kept in LDS (8 B each): 24 KiB per workgroup
+constexpr int BVH2_STACK = 64;       // k_trace2 (the reference uses 32 unchecked, util/misc.cuh:19)
+
+// per-slot flag bits (RenderArgs::st[].z low byte)
+enum : uint32_t { F_DONE = 1, F_HAS_RAY = 2, F_PENDING = 4, F_AHEAD = 8 };
+// queue counters (RenderArgs::qcount)
+enum : int { QC_EXT_FRONT = 0, QC_EXT_BACK = 1, QC_SHADOW = 2, QC_ACTIVE = 3, QC_COUNT = 4 };
+
+struct RenderArgs {
+  uint32_t n_slots, width, height, tiles_x, tiles_y, tile_rank, tile_world;
+  uint32_t rng_mode, seed, sample_begin;
+  uint32_t spp, spl, batch, max_depth, adaptive, glass_int_abs, n_lights;
+  float tol;
+  DCamera cam;
+  // per-slot path state (SoA, 16-byte records)
+  uint4 *st;            // rng state | sample index | flags + shadow count << 8 | bounce index
+  float4 *mask;         // color_mask
+  float4 *total;        // total_color of the sample in flight, .w = s1 (raytracer.cuh:98)
+  float4 *accum;        // sum of finished samples
+  float4 *dmask;        // color_mask at the hit whose shadow rays are in flight
+  float4 *ray_o, *ray_d, *hit;            // extension ray (origin|min_t, ctor direction|max_t) and its hit (t, b.y, b.z, idx)
+  float4 *sh_o, *sh_d, *sh_c;             // shadow rays, entry e = k * n_slots + slot, and their contributions
+  uint32_t *sh_occ;
+  uint32_t *ext_queue, *sh_queue, *qcount;
+  unsigned long long *ray_stats;          // closest, shadow, paths
+  float4 *out_accum;                      // width * height, (sum rgb, divisor)
+  const float4 *tri_nrm;                  // 3 float4 per triangle: n1 n2 n3, material, original index
+  const float *mats;                      // 9 dwords per material (mirt_bsdf)
+  const float *lights;                    // 17 dwords per light (mirt_light)
+};
+
+struct TraceArgs {
+  const float4 *nodes4;                   // 8 float4 per wide node
+  const float4 *nodes2;                   // 2 float4 per reference node
+  const float4 *tris;                     // 3 float4 per triangle: p1, e1, e2
+  const uint2 *big;                       // (start, count) of leaves with more than 15 primitives
+  const float4 *ray_o, *ray_d;
+  const uint32_t *queue, *qcount;
+  int qc_front, qc_back;                  // indices into qcount; qc_back < 0: no back range
+  uint32_t qcap;                          // the back range ends at queue[qcap - 1]
+  float4 *hit;                            // closest-hit output
+  uint32_t *occ;                          // any-hit output
+  float *any_t;                           // any-hit: max_t after the walk (probe only, may be null)
+  uint32_t *work_head;
+  uint2 *ovf;
+  uint32_t ovf_depth;
+  uint32_t *redo_queue, *redo_count;
+  uint32_t redo;                          // 1: k_trace2 walks redo_queue[0 .. *redo_count)
+  uint32_t *error_flag;
+  unsigned long long *redo_stat;          // counts rays re-traced by the reference walk (may be null)
+};
+
+hipError_t launch_init(const RenderArgs &a, hipStream_t st);
+hipError_t launch_logic(const RenderArgs &a, hipStream_t st);
+hipError_t launch_probe_primary(const RenderArgs &a, hipStream_t st);
+hipError_t launch_gather_primary(const RenderArgs &a, int32_t *idx, uint32_t *tb, hipStream_t st);
+hipError_t launch_iota(uint32_t *q, uint32_t n, hipStream_t st);
+hipError_t launch_tonemap(const void *accum, uint32_t n, const float *table, int32_t *rgb, hipStream_t st);
+hipError_t launch_trace(const TraceArgs &a, bool any, uint32_t traversal, uint32_t grid_blocks, hipStream_t st);
+size_t trace4_lds_bytes();
+int trace4_blocks_per_cu();
+
+}  // namespace mirt
