@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json: Mrays/s (all bounces) + ms/frame on conference* 1080p 64 spp depth 8.
+
+A "step" is one whole frame of the hot path: wavefront path tracing of every (pixel, sample) of the frame with the scene
+(BVH, triangles, materials, lights) already resident in HBM, ending with the float accumulation buffer summed onto rank 0
+and tonemapped into host memory.  With N > 1 the frame is split over the ranks by interleaved 8x8 tiles (one process per
+GPU, `torch.distributed` over RCCL); the only collective is the sum-reduce of the accumulation buffer.
+
+    python bench.py [--gpus N --steps K --warmup W]       # N > 1: launched under torch.distributed.run by the driver
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the closest-hit wide-BVH traversal) against HBM
+peak: algorithmic bytes = rays x (160 B of wavefront state + node visits x 128 B + triangle tests x 48 B),
+time = that kernel's launches measured with HIP events on its own stream inside the timed steps.  `cpu_baseline` times the
+reference's own CPU path (oracle/_ref, built from /root/reference in the build container) -- or the C oracle when that
+library is absent -- on a bounded crop of the same workload, on the box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+B_STATE_CLOSEST = 160          # ray r/w 64 + hit r/w 32 + path state r/w 64
+S_NODE = 128                   # bytes of one wide node
+S_TRI = 48                     # bytes of one packed triangle (p1, e1, e2)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="conference*")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--rng", type=int, default=1, help="0 reference xorshift stream, 1 counter-based (default)")
+    ap.add_argument("--traversal", type=int, default=0)
+    ap.add_argument("--partition", default="tile", choices=["tile", "spp"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(scene_data, args):
+    """Reference CPU path on a bounded sample of the same workload: quarter-resolution frame, 8 spp, same depth."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpulibs import CpuTracer, ref_available
+
+    threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+    w, h, spp = args.width // 4, args.height // 4, 8
+    cam = scene_data.camera
+    kw = dict(spp=spp, spl=1, batch=spp + 1, tol=0.0, depth=args.depth, nthreads=threads)
+    orc = CpuTracer("oracle").load(scene_data)
+    orc.set_camera(cam)
+    orc.render(w, h, **kw)
+    rays = orc.last["closest"] + orc.last["shadow"]
+    kind, secs = "port", orc.last["seconds"]
+    if ref_available():
+        ref = CpuTracer("ref").load(scene_data)
+        ref.set_camera(cam)
+        ref.render(w, h, **kw)
+        kind, secs = "reference", ref.last["seconds"]
+        ref.close()
+    orc.close()
+    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": kind,
+            "sample": f"{scene_data.name} {w}x{h}, {spp} spp, depth {args.depth}, {rays} rays in {secs:.2f} s "
+                      f"(rays counted by the C oracle, whose control flow is bit-identical)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from raytracer_amd import capi, scenes
+
+    capi.init(local_rank)
+    sd = scenes.WORKLOADS[args.workload]()
+    sd.camera = sd.camera.for_aspect(args.width, args.height)
+    t0 = time.time()
+    scene = capi.Scene(sd)
+    build_s = time.time() - t0
+    w, h = args.width, args.height
+    accum = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+
+    opt = dict(rng_mode=args.rng, traversal=args.traversal, profile=True)
+    if world > 1 and args.partition == "tile":
+        opt.update(tile_rank=rank, tile_world=world)
+    elif world > 1:
+        per = args.spp // world
+        opt.update(rng_mode=1, sample_begin=rank * per, sample_count=per if rank < world - 1 else args.spp - per * (world - 1))
+    kw = dict(spp=args.spp, spl=1, batch=args.spp + 1, tol=0.0, depth=args.depth)   # fixed spp: no adaptive stop
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        st = scene.render_accum(w, h, accum.data_ptr(), **kw, **opt)
+        if dist is not None:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        if rank == 0:
+            capi.tonemap(accum.data_ptr(), w, h)          # film in host memory
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    stats = [step() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    rays = sum(s["closest_rays"] + s["shadow_rays"] for s in stats)
+    tl = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if dist is not None:
+        tmax = tl.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tl, op=dist.ReduceOp.SUM)
+        elapsed, rays = float(tmax[0]), float(tl[1])
+    ms_per_step = 1e3 * elapsed / max(1, args.steps)
+
+    if rank == 0:
+        # traversal work per ray (counting build of the same kernels, one untimed reduced-spp frame)
+        cnt = scene.render_accum(w, h, accum.data_ptr(), spp=min(4, args.spp), spl=1, batch=args.spp + 1, tol=0.0,
+                                 depth=args.depth, **{**opt, "count": True, "sample_count": 0, "sample_begin": 0})
+        n_node = cnt["closest_node_visits"] / max(1, cnt["closest_rays"])
+        n_tri = cnt["closest_tri_tests"] / max(1, cnt["closest_rays"])
+        b_ray = B_STATE_CLOSEST + n_node * S_NODE + n_tri * S_TRI
+        launches = sum(s["closest_launches"] for s in stats)
+        k_ms = sum(s["trace_closest_ms"] for s in stats)
+        k_rays = sum(s["closest_rays"] for s in stats)
+        avg_launch_ms = k_ms / max(1, launches)
+        achieved = (k_rays * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (all bounces), conference.obj stand-in 1080p 64spp",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "ms_per_frame": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (procedural stand-in scene: the reference's .obj meshes are absent)",
+            "config": {"workload": f"{args.workload} {sd.n} tris, {w}x{h}, {args.spp} spp, depth {args.depth}, "
+                                   f"2 lights, rng {'counter' if opt['rng_mode'] else 'xorshift'}, "
+                                   f"traversal {args.traversal}",
+                       "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
+                       "scene_build_s": build_s},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_trace4<closest>", "avg_launch_ms": avg_launch_ms, "launches": launches,
+                         "bytes_per_ray": b_ray, "node_visits_per_ray": n_node, "tri_tests_per_ray": n_tri,
+                         "kernel_rays_per_s": k_rays / (k_ms * 1e-3) if k_ms > 0 else 0.0,
+                         "shadow_kernel_ms": sum(s["trace_shadow_ms"] for s in stats),
+                         "logic_kernel_ms": sum(s["logic_ms"] for s in stats),
+                         "closest_kernel_ms": k_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, args)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,7 +77,7 @@ typedef struct mirt_options {
   uint32_t sample_begin;    /* rng_mode 1 only: first sample index of this process's spp slice */
   uint32_t sample_count;    /* rng_mode 1 only: samples in the slice; 0 = samples_per_pixel */
   uint32_t glass_int_abs;   /* 1 = reproduce the g++ build's integer abs() in GLASS (bsdf.cuh:213) */
-  uint32_t reserved[8];
+  uint32_t reserved[8];     /* [0]: bit 0 = per-launch event timing into mirt_stats, bit 1 = count node visits / triangle tests */
 } mirt_options;
 
 typedef struct mirt_stats {
@@ -90,6 +90,10 @@ typedef struct mirt_stats {
   double render_ms;         /* first launch -> accumulation buffer complete, device events */
   double trace_closest_ms, trace_shadow_ms, logic_ms;   /* per-kernel sums, device events */
   double total_ms;          /* wall: entry -> outputs in host memory */
+  /* filled when opts->reserved[0] has bit 0 (time every launch with stream events) / bit 1 (count traversal work) */
+  uint32_t closest_launches, shadow_launches;         /* launches of the wide-BVH traversal kernel that were timed */
+  uint64_t closest_node_visits, closest_tri_tests;    /* wide nodes fetched / triangles tested by closest-hit rays */
+  uint64_t shadow_node_visits, shadow_tri_tests;
 } mirt_stats;
 
 typedef struct mirt_scene mirt_scene;

@@ -52,7 +52,9 @@ class Stats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64),
                 ("exact_fallback_rays", C.c_uint64), ("iterations", C.c_uint32), ("tonemap_table_exact", C.c_uint32),
                 ("render_ms", C.c_double), ("trace_closest_ms", C.c_double), ("trace_shadow_ms", C.c_double),
-                ("logic_ms", C.c_double), ("total_ms", C.c_double)]
+                ("logic_ms", C.c_double), ("total_ms", C.c_double), ("closest_launches", C.c_uint32),
+                ("shadow_launches", C.c_uint32), ("closest_node_visits", C.c_uint64), ("closest_tri_tests", C.c_uint64),
+                ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -194,12 +196,12 @@ class Scene:
 
     @staticmethod
     def options(rng_mode=0, seed=0, traversal=0, tile_rank=0, tile_world=1, sample_begin=0, sample_count=0,
-                glass_int_abs=0, profile=False):
+                glass_int_abs=0, profile=False, count=False):
         o = Options()
         o.rng_mode, o.seed, o.traversal = rng_mode, seed, traversal
         o.tile_rank, o.tile_world = tile_rank, tile_world
         o.sample_begin, o.sample_count, o.glass_int_abs = sample_begin, sample_count, glass_int_abs
-        o.reserved[0] = 1 if profile else 0
+        o.reserved[0] = (1 if profile else 0) | (2 if count else 0)
         return o
 
     def render(self, w, h, spp=4, spl=1, batch=64, tol=0.05, depth=4, leaf=4, **opt):

@@ -68,7 +68,19 @@ struct Global {
   uint32_t *h_counts = nullptr;          // pinned: RING x QC_COUNT
   hipEvent_t ring_ev[RING] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> pool;          // timing events for profiled renders (recorded without host syncs)
+  size_t pool_used = 0;
+  hipEvent_t pool_next() {
+    if (pool_used == pool.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[pool_used++];
+  }
 } G;
+
+struct Timed { int kind; hipEvent_t a, b; };   // kind 0 logic, 1 closest trace, 2 shadow trace
 
 // control block layout (uint32): qcount[4] | work_head[2] | redo_count[2] | error flag
 enum { CTRL_QCOUNT = 0, CTRL_WORK = 4, CTRL_REDO = 6, CTRL_ERR = 8, CTRL_WORDS = 12 };
@@ -141,6 +153,7 @@ void mirt_shutdown(void) {
   if (G.ev0) (void) hipEventDestroy(G.ev0);
   if (G.ev1) (void) hipEventDestroy(G.ev1);
   if (G.h_counts) (void) hipHostFree(G.h_counts);
+  for (auto e: G.pool) (void) hipEventDestroy(e);
   G.d_table.release();
   (void) hipStreamDestroy(G.stream);
   G = Global();
@@ -326,7 +339,7 @@ int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
   HIPCHK(s->redo_q[0].ensure(n * 4));
   HIPCHK(s->redo_q[1].ensure(kn * 4));
   HIPCHK(s->ctrl.ensure(CTRL_WORDS * 4));
-  HIPCHK(s->ray_stats.ensure(4 * 8));
+  HIPCHK(s->ray_stats.ensure(8 * 8));
   return MIRT_OK;
 }
 
@@ -353,6 +366,7 @@ TraceArgs closest_args(mirt_scene *s, uint32_t n_slots) {
   t.redo_count = ctrl + CTRL_REDO + 0;
   t.error_flag = ctrl + CTRL_ERR;
   t.redo_stat = s->ray_stats.as<unsigned long long>() + 3;
+  t.count_stat = s->ray_stats.as<unsigned long long>() + 4;
   return t;
 }
 TraceArgs shadow_args(mirt_scene *s) {
@@ -377,23 +391,28 @@ TraceArgs shadow_args(mirt_scene *s) {
   t.redo_count = ctrl + CTRL_REDO + 1;
   t.error_flag = ctrl + CTRL_ERR;
   t.redo_stat = s->ray_stats.as<unsigned long long>() + 3;
+  t.count_stat = s->ray_stats.as<unsigned long long>() + 6;
   return t;
 }
 
-int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, double *ms_acc) {
+int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, std::vector<Timed> *timed, bool count = false) {
   const uint32_t grid = s->trace_threads / TRACE_BLOCK;
-  if (ms_acc) HIPCHK(hipEventRecord(G.ev0, G.stream));
+  Timed tm{any ? 2 : 1, nullptr, nullptr};
+  if (timed) {
+    tm.a = G.pool_next();
+    tm.b = G.pool_next();
+    if (!tm.a || !tm.b) return fail(MIRT_E_DEVICE, "could not create timing events");
+    HIPCHK(hipEventRecord(tm.a, G.stream));
+  }
+  t.count = count ? 1 : 0;
   HIPCHK(launch_trace(t, any, traversal, grid, G.stream));
+  if (timed) {
+    HIPCHK(hipEventRecord(tm.b, G.stream));
+    timed->push_back(tm);
+  }
   if (traversal != 2) {
     t.redo = 1;
     HIPCHK(launch_trace(t, any, 2, 256, G.stream));
-  }
-  if (ms_acc) {
-    HIPCHK(hipEventRecord(G.ev1, G.stream));
-    HIPCHK(hipEventSynchronize(G.ev1));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, G.ev0, G.ev1));
-    *ms_acc += ms;
   }
   return MIRT_OK;
 }
@@ -448,13 +467,17 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   a.tri_nrm = s->tri_nrm.as<float4>(); a.mats = s->mats.as<float>(); a.lights = s->lights.as<float>();
 
   const bool profile = stats && (o.reserved[0] & 1u);
-  double ms_closest = 0, ms_shadow = 0, ms_logic = 0;
+  const bool counting = stats && (o.reserved[0] & 2u);
+  double ms_kind[3] = {0, 0, 0};
+  uint32_t n_kind[3] = {0, 0, 0};
+  std::vector<Timed> timed;
+  G.pool_used = 0;
   hipEvent_t evA, evB;
   HIPCHK(hipEventCreate(&evA));
   HIPCHK(hipEventCreate(&evB));
 
   HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
-  HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, 32, G.stream));
+  HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, 64, G.stream));
   HIPCHK(hipMemsetAsync(s->ctrl.p, 0, CTRL_WORDS * 4, G.stream));
   HIPCHK(hipEventRecord(evA, G.stream));
   uint32_t iters = 0;
@@ -469,22 +492,25 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
         return fail(MIRT_E_DEVICE, "wavefront loop did not terminate");
       }
       HIPCHK(hipMemsetAsync(ctrl, 0, CTRL_ERR * 4, G.stream));          // queue counters, work heads, redo counters
-      if (profile) HIPCHK(hipEventRecord(G.ev0, G.stream));
+      Timed tl{0, nullptr, nullptr};
+      if (profile) {
+        tl.a = G.pool_next();
+        tl.b = G.pool_next();
+        if (!tl.a || !tl.b) return fail(MIRT_E_DEVICE, "could not create timing events");
+        HIPCHK(hipEventRecord(tl.a, G.stream));
+      }
       HIPCHK(launch_logic(a, G.stream));
       if (profile) {
-        HIPCHK(hipEventRecord(G.ev1, G.stream));
-        HIPCHK(hipEventSynchronize(G.ev1));
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, G.ev0, G.ev1));
-        ms_logic += ms;
+        HIPCHK(hipEventRecord(tl.b, G.stream));
+        timed.push_back(tl);
       }
       const int slot = (int) (it % RING);
       HIPCHK(hipMemcpyAsync(G.h_counts + slot * QC_COUNT, ctrl + CTRL_QCOUNT, QC_COUNT * 4, hipMemcpyDeviceToHost, G.stream));
       HIPCHK(hipEventRecord(G.ring_ev[slot], G.stream));
-      rc = run_trace(s, tc, false, o.traversal, profile ? &ms_closest : nullptr);
+      rc = run_trace(s, tc, false, o.traversal, profile ? &timed : nullptr, counting);
       if (rc) return rc;
       if (K) {
-        rc = run_trace(s, ts, true, o.traversal, profile ? &ms_shadow : nullptr);
+        rc = run_trace(s, ts, true, o.traversal, profile ? &timed : nullptr, counting);
         if (rc) return rc;
       }
       iters++;
@@ -505,9 +531,15 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   (void) hipEventDestroy(evA);
   (void) hipEventDestroy(evB);
   if (err) return fail(MIRT_E_LIMIT, "traversal stack overflow on the device (BVH too deep)");
+  for (const Timed &t: timed) {
+    float tms = 0;
+    HIPCHK(hipEventElapsedTime(&tms, t.a, t.b));
+    ms_kind[t.kind] += tms;
+    n_kind[t.kind]++;
+  }
   if (stats) {
-    unsigned long long rs[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpy(rs, s->ray_stats.p, 32, hipMemcpyDeviceToHost));
+    unsigned long long rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpy(rs, s->ray_stats.p, 64, hipMemcpyDeviceToHost));
     memset(stats, 0, sizeof *stats);
     stats->closest_rays = rs[0];
     stats->shadow_rays = rs[1];
@@ -516,9 +548,15 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     stats->iterations = iters;
     stats->tonemap_table_exact = G.table_exact ? 1 : 0;
     stats->render_ms = ms;
-    stats->trace_closest_ms = ms_closest;
-    stats->trace_shadow_ms = ms_shadow;
-    stats->logic_ms = ms_logic;
+    stats->trace_closest_ms = ms_kind[1];
+    stats->trace_shadow_ms = ms_kind[2];
+    stats->logic_ms = ms_kind[0];
+    stats->closest_launches = n_kind[1];
+    stats->shadow_launches = n_kind[2];
+    stats->closest_node_visits = rs[4];
+    stats->closest_tri_tests = rs[5];
+    stats->shadow_node_visits = rs[6];
+    stats->shadow_tri_tests = rs[7];
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   }
   return MIRT_OK;

@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(256) k_trace2(TraceArgs a) {
 // -------------------------------------------------------------------------------------------- k_trace4 (wide BVH)
 // MODE 0: children sorted near-to-far (ordered traversal; equal-t hits resolved by the tie rule "larger flat index wins",
 //         which is what the reference's fixed visiting order produces);  MODE 1: children in the reference's DFS order.
-template<bool ANY, int MODE>
+template<bool ANY, int MODE, bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
   extern __shared__ uint2 lds_stack[];                    // [LDS_STACK][TRACE_BLOCK]
   const uint32_t tid = threadIdx.x;
@@ -461,6 +461,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
   bool active = false, exhausted = false;
   uint32_t cur = CHILD_EMPTY;
   int sp = 0;
+  uint32_t n_nodes = 0, n_tris = 0;
 
   auto push = [&](uint32_t ref, float tmn) {
     if (sp < LDS_STACK) lds_stack[sp * TRACE_BLOCK + tid] = make_uint2(ref, f2u(tmn));
@@ -516,6 +517,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
     // ---------------------------------------------------------------- inner nodes
     while (active && cur != CHILD_EMPTY && !(cur & CHILD_LEAF)) {
       const float4 *np = a.nodes4 + 8 * (size_t) cur;
+      if (COUNT) n_nodes++;
       const float4 LX = np[0], LY = np[1], LZ = np[2], HX = np[3], HY = np[4], HZ = np[5];
       const float4 CHf = np[6];
       const float lox[4] = {LX.x, LX.y, LX.z, LX.w}, loy[4] = {LY.x, LY.y, LY.z, LY.w}, loz[4] = {LZ.x, LZ.y, LZ.z, LZ.w};
@@ -574,6 +576,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
       bool found = false, irregular = false;
       for (uint32_t i = start; i < start + cnt; i++) {
         float t, by, bz;
+        if (COUNT) n_tris++;
         if (tri_test(a.tris, i, r, r.best_t, t, by, bz)) {
           if (!(fabsf(t) < MIRT_INF)) { irregular = true; break; }        // accepted NaN / inf hit
           // ordered traversal may meet equal-t hits in any order: the reference ends with the largest flat index
@@ -604,6 +607,17 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
         a.hit[r.id] = make_float4(r.best_t, r.b1, r.b2, u2f((uint32_t) r.best_idx));
       }
       active = false;
+    }
+  }
+  if (COUNT) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      n_nodes += __shfl_xor(n_nodes, o);
+      n_tris += __shfl_xor(n_tris, o);
+    }
+    if ((tid & 63) == 0) {
+      atomicAdd(a.count_stat + 0, (unsigned long long) n_nodes);
+      atomicAdd(a.count_stat + 1, (unsigned long long) n_tris);
     }
   }
 }
@@ -710,7 +724,7 @@ size_t trace4_lds_bytes() { return (size_t) LDS_STACK * TRACE_BLOCK * sizeof(uin
 
 int trace4_blocks_per_cu() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace4<false, 0>, TRACE_BLOCK, trace4_lds_bytes()) != hipSuccess || nb < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace4<false, 0, false>, TRACE_BLOCK, trace4_lds_bytes()) != hipSuccess || nb < 1)
     nb = 2;
   return nb;
 }
@@ -724,11 +738,14 @@ hipError_t launch_trace(const TraceArgs &a, bool any, uint32_t traversal, uint32
     const size_t lds = trace4_lds_bytes();
     if (any) {
       // the boolean of an any-hit query does not depend on the visiting order: one instantiation serves both modes
-      k_trace4<true, 1><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      if (a.count) k_trace4<true, 1, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      else k_trace4<true, 1, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
     } else if (traversal == 0) {
-      k_trace4<false, 0><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      if (a.count) k_trace4<false, 0, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      else k_trace4<false, 0, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
     } else {
-      k_trace4<false, 1><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      if (a.count) k_trace4<false, 1, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      else k_trace4<false, 1, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
     }
   }
   LAUNCH_CHECK();

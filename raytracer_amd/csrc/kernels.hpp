@@ -59,6 +59,8 @@ struct TraceArgs {
   uint32_t redo;                          // 1: k_trace2 walks redo_queue[0 .. *redo_count)
   uint32_t *error_flag;
   unsigned long long *redo_stat;          // counts rays re-traced by the reference walk (may be null)
+  unsigned long long *count_stat;         // [0] node visits, [1] triangle tests (counting launches only)
+  uint32_t count;
 };
 
 hipError_t launch_init(const RenderArgs &a, hipStream_t st);
