@@ -1,0 +1,48 @@
+"""Multi-GPU partition rules of the render path (one process per GPU, torch.distributed over RCCL).
+
+The path shards without any data-path collective inside the frame: every (pixel, sample) is independent.  Two orthogonal
+partitions, both ending in ONE sum-reduce of the float4 accumulation buffer (sum r, sum g, sum b, divisor):
+  * tile: 8x8-pixel tiles dealt round-robin, tile t belongs to rank t % world (exactly what libmirt does for
+    mirt_options.tile_rank / tile_world); the other ranks contribute zeros, so the sum is bit-identical to one GPU;
+  * spp : rank r renders samples [begin_r, begin_r + count_r) of every pixel (counter-based RNG only); float sums are
+    re-associated, so the result matches one GPU to rounding.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TILE = 8
+
+
+def tile_owner(width, height, world):
+    """(h, w) int array: the rank that owns each pixel under the tile partition."""
+    tx = np.arange(width) // TILE
+    ty = np.arange(height) // TILE
+    tiles_x = (width + TILE - 1) // TILE
+    return ((ty[:, None] * tiles_x + tx[None, :]) % max(1, world)).astype(np.int32)
+
+
+def spp_slices(spp, world):
+    """[(begin, count)] per rank; the last rank takes the remainder.  Ranks with count 0 render nothing."""
+    per = spp // world
+    out = []
+    for r in range(world):
+        cnt = per if r < world - 1 else spp - per * (world - 1)
+        out.append((r * per, cnt))
+    return out
+
+
+def partition_options(kind, rank, world, spp):
+    """kwargs for capi.Scene.render_accum for this rank."""
+    if world <= 1:
+        return {}
+    if kind == "tile":
+        return dict(tile_rank=rank, tile_world=world)
+    begin, count = spp_slices(spp, world)[rank]
+    return dict(rng_mode=1, sample_begin=begin, sample_count=count)
+
+
+def reduce_accum(accum, dist, dst=0):
+    """Sum the per-rank accumulation buffers onto `dst` (RCCL reduce on GPUs; gloo in the CPU tests)."""
+    dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+    return accum

@@ -1,0 +1,73 @@
+"""C oracle vs the reference's own headers (oracle/_ref/libref*.so), bitwise, on scenes and rays that are NOT in the golden
+set.  Skipped where the reference build is absent (a fresh checkout without /root/reference)."""
+import numpy as np
+import pytest
+
+from cpulibs import CpuTracer, ref_available
+from raytracer_amd import scenes
+
+pytestmark = pytest.mark.skipif(not ref_available(), reason="oracle/_ref/libref.so not built (reference not mounted)")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return CpuTracer("ref")
+
+
+@pytest.mark.parametrize("make,res,kw", [
+    (lambda: scenes.cornell_scene(1, "mixed"), (48, 36), dict(spp=6, depth=5, spl=1)),
+    (lambda: scenes.sportscar_scene(6000), (64, 36), dict(spp=4, depth=8)),
+    (lambda: scenes.random_soup(3000, 7), (48, 48), dict(spp=3, depth=4)),
+    (lambda: scenes.blob_scene(96, 48), (64, 64), dict(spp=2, depth=2, batch=1, tol=0.3)),
+])
+def test_scene_bitwise(oracle, ref, make, res, kw):
+    sc = make()
+    w, h = res
+    oracle.set_glass_float_abs(0)
+    oracle.load(sc)
+    ref.load(sc)
+    n1, f1 = oracle.bvh()
+    n2, f2 = ref.bvh()
+    assert n1.shape == n2.shape and (n1 == n2).all() and (f1 == f2).all()
+    assert oracle.info() == ref.info()
+    i1, t1 = oracle.primary_hits(w, h)
+    i2, t2 = ref.primary_hits(w, h)
+    assert (i1 == i2).all() and (t1 == t2).all()
+    assert (oracle.render(w, h, **kw) == ref.render(w, h, **kw)).all()
+
+
+def test_float_abs_variant(oracle):
+    sc = scenes.cornell_scene(1, "mixed")
+    rf = CpuTracer("ref", "_fabs").load(sc)
+    oracle.set_glass_float_abs(1)
+    oracle.load(sc)
+    a = oracle.render(48, 36, spp=6, depth=6)
+    oracle.set_glass_float_abs(0)
+    assert (a == rf.render(48, 36, spp=6, depth=6)).all()
+
+
+def test_random_rays_incl_degenerate(oracle, ref):
+    sc = scenes.conference_scene(8000)
+    oracle.load(sc)
+    ref.load(sc)
+    rng = np.random.default_rng(3)
+    n = 4000
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, :3] = rng.uniform(-6, 6, (n, 3))
+    rays[:, 3:6] = rng.normal(size=(n, 3))
+    rays[:, 6] = 1e-5
+    rays[:, 7] = np.inf
+    rays[:500, 3] = 0                                  # 0 * inf slabs
+    rays[500:700, 3:6] = [0, -1, 0]                    # axis-aligned, like a {0,-1,0} light
+    rays[700:800, 0] = 5.0                             # origin in a wall plane
+    rays[800:900, 7] = rng.uniform(0.1, 4, 100)
+    for anyhit in (False, True):
+        a = oracle.trace(rays, anyhit=anyhit)
+        b = ref.trace(rays, anyhit=anyhit)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+
+
+def test_multithreaded_ref_equals_serial(ref):
+    sc = scenes.cornell_scene(1, "diffuse")
+    ref.load(sc)
+    assert (ref.render(40, 30, spp=4, depth=3, nthreads=1) == ref.render(40, 30, spp=4, depth=3, nthreads=4)).all()
