@@ -319,3 +319,34 @@ def test_one_pixel_and_tiny_scene(mirt, oracle):
         b = oracle.primary_hits(w, h)
         assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
     s.close()
+
+
+def test_cpp_host_mirror_app_renders_the_same_film(mirt, tmp_path):
+    """apps/render.cpp is written against the reference's host API (PathTracer, factories, Generator::room) via
+    include/raytracer_amd/pathtracer.hpp; its BMP must equal the film the ctypes path renders for the same scene."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    app = os.path.join(root, "raytracer_amd", "render_app")
+    assert os.path.exists(app), "build it with make -C raytracer_amd/csrc all"
+    out = str(tmp_path / "app.bmp")
+    w, h, spp, depth = 64, 36, 2, 5
+    r = subprocess.run([app, out, "--w", str(w), "--h", str(h), "--spp", str(spp), "--depth", str(depth)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "Image saved" in r.stdout, r.stdout + r.stderr
+    rp, rn, wall = scenes.room_triangles(4, 3, 4)
+    wall_mat = {0: 0, 1: 0, 2: 1, 3: 2, 4: 0, 5: 0}
+    pos = np.concatenate([rp, np.array([[-.8, 0, .5, .8, 0, .5, 0, 1.6, .2], [-.5, 2.999, -.5, .5, 2.999, -.5, .5, 2.999, .5]], np.float32)])
+    nrm = np.concatenate([rn, np.array([[0, .2, -1] * 3, [0, -1, 0] * 3], np.float32)])
+    mat = np.concatenate([[wall_mat[int(k)] for k in wall], [3, 4]]).astype(np.uint32)
+    sd = scenes.SceneData("app", pos, nrm, mat, np.array([scenes.WHITE, scenes.RED, scenes.GREEN, scenes.MIRROR, scenes.emission(4, 4, 4)]),
+                          np.array([scenes.area_light((12, 12, 12), (0, 2.99, 0), (0, -1, 0), (1, 0, 0), (0, 0, 1)),
+                                    scenes.point_light((1.5, 1.5, 1.5), (1.5, 2.5, -1.5))]),
+                          scenes.Camera((0, 1.5, -1.95), (0, 1.2, 0), hfov=70, vfov=float(np.float32(70) * np.float32(h) / np.float32(w)))).finalize()
+    s = mirt.Scene(sd)
+    img = s.render(w, h, spp=spp, batch=spp + 1, depth=depth)
+    ref_bmp = str(tmp_path / "py.bmp")
+    mirt.save_bmp(ref_bmp, img)
+    assert open(out, "rb").read() == open(ref_bmp, "rb").read()
+    s.close()
