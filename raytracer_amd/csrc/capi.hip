@@ -2,6 +2,7 @@
 // compute entry point needs a HIP device and fails with MIRT_E_DEVICE without one.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -90,14 +91,14 @@ enum { CTRL_QCOUNT = 0, CTRL_WORK = 4, CTRL_REDO = 6, CTRL_ERR = 8, CTRL_WORDS =
 struct mirt_scene {
   HostBVH bvh;
   uint32_t n_tris = 0, n_mats = 0, n_lights = 0;
-  DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big;
+  DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big, nodes4f, trisf;
   uint32_t ovf_depth = 0;
   uint32_t trace_threads = 0;
   // work buffers (sized per render)
   DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2];
   DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t;
   size_t device_bytes() const {
-    const DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &st, &mask, &total, &accum, &dmask,
+    const DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &nodes4f, &trisf, &st, &mask, &total, &accum, &dmask,
                            &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0],
                            &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t};
     size_t s = 0;
@@ -105,7 +106,7 @@ struct mirt_scene {
     return s;
   }
   void release_all() {
-    DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &st, &mask, &total, &accum, &dmask,
+    DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &nodes4f, &trisf, &st, &mask, &total, &accum, &dmask,
                      &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0], &redo_q[1],
                      &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t};
     for (auto *b: all) b->release();
@@ -195,11 +196,22 @@ int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t
     t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
     t[3] = p[3] - p[0]; t[4] = p[4] - p[1]; t[5] = p[5] - p[2];       // e1 = p2 - p1 (primitives.cuh:138)
     t[6] = p[6] - p[0]; t[7] = p[7] - p[1]; t[8] = p[8] - p[2];       // e2 = p3 - p1 (primitives.cuh:139)
-    t[9] = t[10] = t[11] = 0.f;
+    memcpy(t + 9, &f, 4);                                             // its own flat index (uniform with the fast tree's copy)
+    t[10] = t[11] = 0.f;
     memcpy(m, q, 9 * sizeof(float));
     memcpy(m + 9, &tri_mat[o], 4);
     memcpy(m + 10, &o, 4);
     m[11] = 0.f;
+  }
+  // the ordered traversal's own tree (binned SAH) over the same triangles, in its own order
+  std::vector<float> trif((size_t) n_tris * 12);
+  {
+    std::vector<float> flat_pos((size_t) n_tris * 9);
+    for (uint32_t f = 0; f < n_tris; f++)
+      memcpy(&flat_pos[(size_t) f * 9], tri_pos + 9 * (size_t) s->bvh.flat_to_orig[f], 9 * sizeof(float));
+    build_fast_tree(flat_pos.data(), n_tris, s->bvh);
+    for (uint32_t j = 0; j < n_tris; j++)
+      memcpy(&trif[(size_t) j * 12], &tri[(size_t) s->bvh.fast_to_flat[j] * 12], 12 * sizeof(float));
   }
   int rc = MIRT_OK;
   auto up = [&](DevBuf &b, const void *src, size_t bytes) -> bool {
@@ -209,12 +221,14 @@ int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t
   bool ok = up(s->tris, tri.data(), tri.size() * 4) && up(s->tri_nrm, nrm.data(), nrm.size() * 4) &&
             up(s->nodes4, s->bvh.nodes4.data(), s->bvh.nodes4.size() * sizeof(Node4)) &&
             up(s->nodes2, s->bvh.nodes2.data(), s->bvh.nodes2.size() * sizeof(Node2)) &&
+            up(s->nodes4f, s->bvh.nodes4f.data(), s->bvh.nodes4f.size() * sizeof(Node4)) &&
+            up(s->trisf, trif.data(), trif.size() * 4) &&
             up(s->mats, mats, (size_t) n_mats * sizeof(mirt_bsdf)) &&
             up(s->big, s->bvh.big.empty() ? (const void *) mats : (const void *) s->bvh.big.data(), s->bvh.big.empty() ? 8 : s->bvh.big.size() * 4) &&
             up(s->lights, lights ? (const void *) lights : (const void *) mats, n_lights ? (size_t) n_lights * sizeof(mirt_light) : 4);
   if (ok) {
     s->trace_threads = (uint32_t) (G.n_cu * G.blocks_per_cu * TRACE_BLOCK);
-    int need = 3 * ((int) s->bvh.depth4 + 2) - LDS_STACK + 1;
+    int need = 3 * ((int) std::max(s->bvh.depth4, s->bvh.depth4f) + 2) - LDS_STACK + 1;
     s->ovf_depth = (uint32_t) (need > 1 ? need : 1);
     ok = s->ovf.ensure((size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
   }
@@ -343,13 +357,15 @@ int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
   return MIRT_OK;
 }
 
-TraceArgs closest_args(mirt_scene *s, uint32_t n_slots) {
+TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal) {
   TraceArgs t;
   memset(&t, 0, sizeof t);
   uint32_t *ctrl = s->ctrl.as<uint32_t>();
-  t.nodes4 = s->nodes4.as<float4>();
+  t.nodes4 = traversal == 0 ? s->nodes4f.as<float4>() : s->nodes4.as<float4>();
   t.nodes2 = s->nodes2.as<float4>();
-  t.tris = s->tris.as<float4>();
+  t.tris = traversal == 0 ? s->trisf.as<float4>() : s->tris.as<float4>();
+  t.tris2 = s->tris.as<float4>();
+  t.require_unit = traversal == 0 ? 1 : 0;
   t.big = s->big.as<uint2>();
   t.ray_o = s->ray_o.as<float4>();
   t.ray_d = s->ray_d.as<float4>();
@@ -369,13 +385,15 @@ TraceArgs closest_args(mirt_scene *s, uint32_t n_slots) {
   t.count_stat = s->ray_stats.as<unsigned long long>() + 4;
   return t;
 }
-TraceArgs shadow_args(mirt_scene *s) {
+TraceArgs shadow_args(mirt_scene *s, uint32_t traversal) {
   TraceArgs t;
   memset(&t, 0, sizeof t);
   uint32_t *ctrl = s->ctrl.as<uint32_t>();
-  t.nodes4 = s->nodes4.as<float4>();
+  t.nodes4 = traversal == 0 ? s->nodes4f.as<float4>() : s->nodes4.as<float4>();
   t.nodes2 = s->nodes2.as<float4>();
-  t.tris = s->tris.as<float4>();
+  t.tris = traversal == 0 ? s->trisf.as<float4>() : s->tris.as<float4>();
+  t.tris2 = s->tris.as<float4>();
+  t.require_unit = traversal == 0 ? 1 : 0;
   t.big = s->big.as<uint2>();
   t.ray_o = s->sh_o.as<float4>();
   t.ray_d = s->sh_d.as<float4>();
@@ -484,7 +502,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   if (part.n_slots) {
     HIPCHK(launch_init(a, G.stream));
     const uint64_t max_iters = (uint64_t) a.spp * ((uint64_t) a.max_depth + 3) + 8;
-    const TraceArgs tc = closest_args(s, part.n_slots), ts = shadow_args(s);
+    const TraceArgs tc = closest_args(s, part.n_slots, o.traversal), ts = shadow_args(s, o.traversal);
     bool done = false;
     for (uint64_t it = 0; !done; it++) {
       if (it >= max_iters + RING) {
@@ -630,7 +648,7 @@ int mirt_primary_hits(mirt_scene *s, const mirt_camera *camera, const mirt_optio
   HIPCHK(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, G.stream));
   HIPCHK(launch_init(a, G.stream));
   HIPCHK(launch_probe_primary(a, G.stream));
-  rc = run_trace(s, closest_args(s, part.n_slots), false, o.traversal, nullptr);
+  rc = run_trace(s, closest_args(s, part.n_slots, o.traversal), false, o.traversal, nullptr);
   if (rc) return rc;
   HIPCHK(launch_gather_primary(a, s->probe_idx.as<int32_t>(), s->probe_t.as<uint32_t>(), G.stream));
   HIPCHK(hipMemcpyAsync(idx_out, s->probe_idx.p, n * 4, hipMemcpyDeviceToHost, G.stream));
@@ -666,14 +684,14 @@ int mirt_trace(mirt_scene *s, const float *rays, uint32_t n, int any_hit, uint32
     HIPCHK(hipMemcpyAsync(s->sh_d.p, rd.data(), (size_t) n * 16, hipMemcpyHostToDevice, G.stream));
     HIPCHK(launch_iota(s->sh_queue.as<uint32_t>(), n, G.stream));
     HIPCHK(hipMemcpyAsync(ctrl + CTRL_QCOUNT + QC_SHADOW, &n, 4, hipMemcpyHostToDevice, G.stream));
-    t = shadow_args(s);
+    t = shadow_args(s, traversal);
     t.any_t = s->any_t.as<float>();
   } else {
     HIPCHK(hipMemcpyAsync(s->ray_o.p, ro.data(), (size_t) n * 16, hipMemcpyHostToDevice, G.stream));
     HIPCHK(hipMemcpyAsync(s->ray_d.p, rd.data(), (size_t) n * 16, hipMemcpyHostToDevice, G.stream));
     HIPCHK(launch_iota(s->ext_queue.as<uint32_t>(), n, G.stream));
     HIPCHK(hipMemcpyAsync(ctrl + CTRL_QCOUNT + QC_EXT_FRONT, &n, 4, hipMemcpyHostToDevice, G.stream));
-    t = closest_args(s, n);
+    t = closest_args(s, n, traversal);
   }
   HIPCHK(hipStreamSynchronize(G.stream));     // the host staging vectors and &n must outlive the copies
   rc = run_trace(s, t, any_hit != 0, traversal, nullptr);

@@ -146,10 +146,16 @@ inline float half_area(const Node2 &n) {
   return dx * dy + dy * dz + dz * dx;
 }
 
+struct CollapseIO {
+  const std::vector<Node2> &nodes2;
+  std::vector<Node4> &nodes4;
+  std::vector<uint32_t> &big;
+};
+
 struct Collapser {
-  HostBVH &b;
+  CollapseIO b;
   uint32_t max_depth = 0;
-  explicit Collapser(HostBVH &bvh) : b(bvh) {}
+  explicit Collapser(CollapseIO io) : b(io) {}
 
   static void set_child(Node4 &n, int k, const Node2 &box, uint32_t ref) {
     n.lox[k] = box.minp[0]; n.loy[k] = box.minp[1]; n.loz[k] = box.minp[2];
@@ -243,9 +249,165 @@ void collapse_to_wide(HostBVH &bvh) {
   bvh.nodes4.clear();
   bvh.big.clear();
   bvh.nodes4.reserve(bvh.nodes2.size() / 2 + 4);
-  Collapser c(bvh);
+  Collapser c(CollapseIO{bvh.nodes2, bvh.nodes4, bvh.big});
   c.build(0, 0);
   bvh.depth4 = c.max_depth;
+}
+
+// ------------------------------------------------------------------------------------------------ fast tree
+// The tree the ordered traversal (mirt_options.traversal = 0) walks.  It is NOT the reference's: binned-SAH splits over
+// tight per-triangle boxes, leaves of at most 4 triangles, its own triangle order (each packed triangle carries its flat
+// index of the reference order, which is what hit indices and the tie rule are expressed in).  Any tree over the same
+// triangles yields the reference's closest hit (minimum t, ties to the larger flat index) as long as its boxes contain
+// their triangles, which exact min/max of the vertices guarantees.
+namespace {
+
+struct SahBuilder {
+  const float *pos;                       // triangles in FLAT order, 9 floats each
+  std::vector<Box> pbox;
+  std::vector<float> cent;
+  std::vector<uint32_t> order;
+  std::vector<Node2> &out;
+  std::vector<uint32_t> &perm;
+  uint32_t max_leaf;
+  static constexpr int BINS = 16;
+
+  SahBuilder(std::vector<Node2> &o, std::vector<uint32_t> &p) : out(o), perm(p) {}
+
+  static float area(const Box &b) {
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+  static void grow(Box &a, const Box &b) {
+    for (int k = 0; k < 3; k++) {
+      a.lo[k] = std::fmin(a.lo[k], b.lo[k]);
+      a.hi[k] = std::fmax(a.hi[k], b.hi[k]);
+    }
+  }
+  static Box empty() {
+    Box b;
+    for (int k = 0; k < 3; k++) {
+      b.lo[k] = std::numeric_limits<float>::infinity();
+      b.hi[k] = -std::numeric_limits<float>::infinity();
+    }
+    return b;
+  }
+
+  void prepare(uint32_t n) {
+    pbox.resize(n);
+    cent.resize(3 * (size_t) n);
+    order.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+      const float *p = pos + 9 * (size_t) i;
+      Box b = empty();
+      for (int v = 0; v < 3; v++)
+        for (int k = 0; k < 3; k++) {
+          b.lo[k] = std::fmin(b.lo[k], p[3 * v + k]);
+          b.hi[k] = std::fmax(b.hi[k], p[3 * v + k]);
+        }
+      pbox[i] = b;
+      for (int k = 0; k < 3; k++) cent[3 * (size_t) i + k] = 0.5f * (b.lo[k] + b.hi[k]);
+      order[i] = i;
+    }
+  }
+
+  uint32_t build(uint32_t s, uint32_t e) {
+    Box bb = empty(), cb = empty();
+    for (uint32_t i = s; i < e; i++) {
+      grow(bb, pbox[order[i]]);
+      for (int k = 0; k < 3; k++) {
+        float c = cent[3 * (size_t) order[i] + k];
+        cb.lo[k] = std::fmin(cb.lo[k], c);
+        cb.hi[k] = std::fmax(cb.hi[k], c);
+      }
+    }
+    uint32_t id = (uint32_t) out.size();
+    out.emplace_back();
+    for (int k = 0; k < 3; k++) { out[id].minp[k] = bb.lo[k]; out[id].maxp[k] = bb.hi[k]; }
+    const uint32_t n = e - s;
+    if (n <= max_leaf) {
+      out[id].w0 = 0x80000000u | n;
+      out[id].w1 = (uint32_t) perm.size();
+      for (uint32_t i = s; i < e; i++) perm.push_back(order[i]);
+      return id;
+    }
+    // binned SAH over the three axes
+    int best_axis = -1, best_bin = -1;
+    float best_cost = std::numeric_limits<float>::infinity();
+    for (int ax = 0; ax < 3; ax++) {
+      const float lo = cb.lo[ax], ext = cb.hi[ax] - cb.lo[ax];
+      if (!(ext > 0)) continue;
+      Box bins[BINS];
+      uint32_t cnt[BINS];
+      for (int b = 0; b < BINS; b++) { bins[b] = empty(); cnt[b] = 0; }
+      const float scale = BINS / ext;
+      for (uint32_t i = s; i < e; i++) {
+        int b = (int) ((cent[3 * (size_t) order[i] + ax] - lo) * scale);
+        b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+        grow(bins[b], pbox[order[i]]);
+        cnt[b]++;
+      }
+      float ra[BINS];
+      uint32_t rn[BINS];
+      Box acc = empty();
+      uint32_t c = 0;
+      for (int b = BINS - 1; b > 0; b--) { grow(acc, bins[b]); c += cnt[b]; ra[b] = area(acc); rn[b] = c; }
+      acc = empty();
+      c = 0;
+      for (int b = 0; b < BINS - 1; b++) {
+        grow(acc, bins[b]);
+        c += cnt[b];
+        if (c == 0 || rn[b + 1] == 0) continue;
+        float cost = area(acc) * (float) c + ra[b + 1] * (float) rn[b + 1];
+        if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; }
+      }
+    }
+    uint32_t mid;
+    if (best_axis < 0) {
+      mid = s + n / 2;                                   // all centroids coincide: split by count
+    } else {
+      const float lo = cb.lo[best_axis], scale = BINS / (cb.hi[best_axis] - cb.lo[best_axis]);
+      uint32_t i = s, j = e;
+      while (i < j) {
+        int b = (int) ((cent[3 * (size_t) order[i] + best_axis] - lo) * scale);
+        b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+        if (b <= best_bin) i++;
+        else std::swap(order[i], order[--j]);
+      }
+      mid = i;
+      if (mid == s || mid == e) mid = s + n / 2;
+    }
+    uint32_t l = build(s, mid);
+    uint32_t r = build(mid, e);
+    out[id].w0 = l;
+    out[id].w1 = r;
+    return id;
+  }
+};
+
+uint32_t depth_of_nodes(const std::vector<Node2> &n, uint32_t i, uint32_t d) {
+  if (n[i].w0 & 0x80000000u) return d;
+  uint32_t a = depth_of_nodes(n, n[i].w0, d + 1), b = depth_of_nodes(n, n[i].w1, d + 1);
+  return a < b ? b : a;
+}
+
+}  // namespace
+
+void build_fast_tree(const float *tri_pos_flat, uint32_t n, HostBVH &bvh) {
+  std::vector<Node2> n2;
+  n2.reserve((size_t) n);
+  bvh.fast_to_flat.clear();
+  bvh.fast_to_flat.reserve(n);
+  SahBuilder sb(n2, bvh.fast_to_flat);
+  sb.pos = tri_pos_flat;
+  sb.max_leaf = 4;
+  sb.prepare(n);
+  sb.build(0, n);
+  bvh.nodes4f.clear();
+  std::vector<uint32_t> big_unused;
+  Collapser c(CollapseIO{n2, bvh.nodes4f, big_unused});
+  c.build(0, 0);
+  bvh.depth4f = c.max_depth;
 }
 
 }  // namespace mirt

@@ -43,10 +43,16 @@ struct HostBVH {
   std::vector<Node4> nodes4;
   std::vector<uint32_t> big;                 // (start, count) pairs of reference leaves with more than LEAF_MAX primitives
   uint32_t depth4 = 0;
+  // the ordered traversal's own tree (binned SAH) and its triangle order
+  std::vector<Node4> nodes4f;
+  std::vector<uint32_t> fast_to_flat;        // fast-order slot -> flat (reference-order) index
+  uint32_t depth4f = 0;
 };
 
 // tri_pos: n x 9 floats.  Throws std::runtime_error on limits.
 void build_reference_bvh2(const float *tri_pos, uint32_t n, uint32_t max_leaf_size, HostBVH &out);
 void collapse_to_wide(HostBVH &bvh);
+// tri_pos_flat: the triangles in the reference's flat order (n x 9 floats)
+void build_fast_tree(const float *tri_pos_flat, uint32_t n, HostBVH &bvh);
 
 }  // namespace mirt

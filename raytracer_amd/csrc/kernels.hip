@@ -368,9 +368,10 @@ __device__ __forceinline__ void load_ray(const TraceArgs &a, uint32_t id, LaneRa
 // Moeller-Trumbore exactly as primitives.cuh:137-158 evaluates it (e1, e2 are stored: same subtraction, same bits).
 // Returns the reference's accept decision against `max_t`.
 __device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const LaneRay &r, float max_t, float &t,
-                                         float &by, float &bz) {
+                                         float &by, float &bz, uint32_t &flat) {
   const float4 q0 = tris[3 * (size_t) idx], q1 = tris[3 * (size_t) idx + 1], q2 = tris[3 * (size_t) idx + 2];
   const V3 p1 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
+  flat = f2u(q2.y);                   // index of this triangle in the reference's flat order
   const V3 s = vsub(r.o, p1);
   const V3 s1 = vcross(r.d, e2);
   const V3 s2 = vcross(s, e1);
@@ -380,6 +381,29 @@ __device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const
   bz = rc * vdot(s2, r.d);
   const float bx = 1 - by - bz;
   return !(t < 0 || t <= r.min_t || t > max_t || bx < 0 || by < 0 || bz < 0);
+}
+
+// The ordered traversal's variant: same arithmetic and accept decision, plus `near`: the triangle is hit inside its
+// edges at a distance within NEAR (relative) of one of the two limits the accept test compares against.  For such a hit
+// the reference's own outcome hangs on whether ITS leaf box passed `tmin <= tmax` (bbox.cuh:77) in the last ulps, which
+// no other tree can know: the caller hands the ray to the reference walk (k_trace2).
+__device__ __forceinline__ bool tri_test_near(const float4 *tris, uint32_t idx, const LaneRay &r, float max_t, float near_rel,
+                                              float &t, float &by, float &bz, uint32_t &flat, bool &near) {
+  const float4 q0 = tris[3 * (size_t) idx], q1 = tris[3 * (size_t) idx + 1], q2 = tris[3 * (size_t) idx + 2];
+  const V3 p1 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
+  flat = f2u(q2.y);
+  const V3 s = vsub(r.o, p1);
+  const V3 s1 = vcross(r.d, e2);
+  const V3 s2 = vcross(s, e1);
+  const float rc = 1.0f / vdot(s1, e1);
+  t = rc * vdot(s2, e2);
+  by = rc * vdot(s1, s);
+  bz = rc * vdot(s2, r.d);
+  const float bx = 1 - by - bz;
+  const bool inside = !(t < 0 || bx < 0 || by < 0 || bz < 0);
+  const float band = near_rel * fabsf(t);                 // t finite here or the comparisons below are false / handled by the caller
+  near = inside && (fabsf(t - max_t) <= band || fabsf(t - r.min_t) <= band);
+  return inside && !(t <= r.min_t || t > max_t);
 }
 
 // -------------------------------------------------------------------------------------------- k_trace2 (reference walk)
@@ -421,7 +445,8 @@ __global__ void __launch_bounds__(256) k_trace2(TraceArgs a) {
         const uint32_t cnt = w0 & 0x7fffffffu;
         for (uint32_t i = w1; i < w1 + cnt; i++) {
           float t, by, bz;
-          if (tri_test(a.tris, i, r, r.best_t, t, by, bz)) {
+          uint32_t flat;
+          if (tri_test(a.tris2, i, r, r.best_t, t, by, bz, flat)) {
             r.best_t = t; r.b1 = by; r.b2 = bz; r.best_idx = (int32_t) i;
             if (ANY) { found = true; break; }
           }
@@ -444,10 +469,16 @@ __global__ void __launch_bounds__(256) k_trace2(TraceArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------- k_trace4 (wide BVH)
-// MODE 0: children sorted near-to-far (ordered traversal; equal-t hits resolved by the tie rule "larger flat index wins",
-//         which is what the reference's fixed visiting order produces);  MODE 1: children in the reference's DFS order.
+// MODE 0: its own (SAH) tree, children sorted near-to-far.  The nearest hit does not depend on the tree or the order unless
+//         two candidates (or a candidate and the ray's t limits) lie within NEAR of each other; those rays are re-traced
+//         by the reference walk, so the result equals the reference's.  MODE 1: the reference's tree in its DFS order.
 template<bool ANY, int MODE, bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
+  // MODE 0 only.  NEAR: relative width of the "too close to call" band around the accept limits (see tri_test_near);
+  // SLACK: box culling keeps everything up to (1 + NEAR) * limit plus the slab arithmetic's own rounding.
+  constexpr float NEAR = 1.0e-5f;
+  constexpr float SLACK = 1.0f + 2.5e-5f;
+
   extern __shared__ uint2 lds_stack[];                    // [LDS_STACK][TRACE_BLOCK]
   const uint32_t tid = threadIdx.x;
   const uint32_t gtid = blockIdx.x * TRACE_BLOCK + tid;
@@ -474,7 +505,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
     while (sp > 0) {
       sp--;
       uint2 e = (sp < LDS_STACK) ? lds_stack[sp * TRACE_BLOCK + tid] : a.ovf[(size_t) (sp - LDS_STACK) * nthreads + gtid];
-      if (ANY || u2f(e.y) <= r.best_t) { cur = e.x; break; }
+      if (ANY || u2f(e.y) <= (MODE == 0 ? r.best_t * SLACK : r.best_t)) { cur = e.x; break; }
     }
   };
 
@@ -489,10 +520,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
         // non-finite origins, NaN bounds) makes the reference's result depend on its visiting order: defer to k_trace2.
         bool regular = finite3(r.o) && finite3(r.d) && finite3(r.inv) && (r.best_t == r.best_t) &&
                        (r.min_t == r.min_t);
-        if (MODE == 0 && !ANY) {
+        if (a.require_unit) {
           // The reference prunes boxes with t measured along the UN-normalised ctor direction but hits with t along the
           // normalised one (ray.cuh:19-21): unless the two agree (the integrator only makes unit directions) its result
-          // depends on the visiting order, so such rays take the reference walk too.
+          // depends on its own boxes and visiting order, so such rays take the reference walk (traversal 0 only: its
+          // tree is not the reference's).
           const float4 rd = a.ray_d[id];
           const float l2 = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
           regular = regular && (fabsf(l2 - 1.0f) < 1e-4f);
@@ -532,7 +564,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
         const float t1z = (loz[c] - r.o.z) * r.inv.z, t2z = (hiz[c] - r.o.z) * r.inv.z;
         const float tmn = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
         const float tmx = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), r.best_t));
-        const bool hit = (ch[c] != CHILD_EMPTY) && (tmn <= tmx) && (tmx > r.min_t);
+        // MODE 1 keeps the reference's exact comparison (same boxes as the reference: same decisions).  The ordered
+        // traversal walks its own, tighter boxes, where a slab distance and a Moeller-Trumbore distance of the same point
+        // can disagree in the last ulp (coplanar or box-flush triangles): a few ulps of slack keep every box whose
+        // triangles could still pass the reference's accept test; the accept test itself stays exact.
+        const bool hit = (ch[c] != CHILD_EMPTY) &&
+                         (MODE == 0 ? (tmn <= tmx * SLACK && tmx * SLACK > r.min_t) : (tmn <= tmx && tmx > r.min_t));
         key[c] = hit ? tmn : MIRT_INF;
         if (!hit) ch[c] = CHILD_EMPTY;
       }
@@ -577,11 +614,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
       for (uint32_t i = start; i < start + cnt; i++) {
         float t, by, bz;
         if (COUNT) n_tris++;
-        if (tri_test(a.tris, i, r, r.best_t, t, by, bz)) {
+        uint32_t flat;
+        bool acc, near = false;
+        if (MODE == 0) acc = tri_test_near(a.tris, i, r, r.best_t, NEAR, t, by, bz, flat, near);
+        else acc = tri_test(a.tris, i, r, r.best_t, t, by, bz, flat);
+        if (MODE == 0 && near) { irregular = true; break; }               // two candidates (or a candidate and a limit) too close to call
+        if (acc) {
           if (!(fabsf(t) < MIRT_INF)) { irregular = true; break; }        // accepted NaN / inf hit
-          // ordered traversal may meet equal-t hits in any order: the reference ends with the largest flat index
-          if (MODE == 0 && !ANY && t == r.best_t && (int32_t) i < r.best_idx) continue;
-          r.best_t = t; r.b1 = by; r.b2 = bz; r.best_idx = (int32_t) i;
+          r.best_t = t; r.b1 = by; r.b2 = bz; r.best_idx = (int32_t) flat;
           if (ANY) { found = true; break; }
         }
       }
@@ -736,8 +776,11 @@ hipError_t launch_trace(const TraceArgs &a, bool any, uint32_t traversal, uint32
     else k_trace2<false><<<grid_blocks, 256, 0, st>>>(a);
   } else {
     const size_t lds = trace4_lds_bytes();
-    if (any) {
-      // the boolean of an any-hit query does not depend on the visiting order: one instantiation serves both modes
+    if (any && traversal == 0) {
+      // any-hit never sorts children (the boolean does not depend on the order); MODE only selects the slack rule
+      if (a.count) k_trace4<true, 0, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      else k_trace4<true, 0, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+    } else if (any) {
       if (a.count) k_trace4<true, 1, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
       else k_trace4<true, 1, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
     } else if (traversal == 0) {

@@ -43,7 +43,8 @@ struct RenderArgs {
 struct TraceArgs {
   const float4 *nodes4;                   // 8 float4 per wide node
   const float4 *nodes2;                   // 2 float4 per reference node
-  const float4 *tris;                     // 3 float4 per triangle: p1, e1, e2
+  const float4 *tris;                     // triangles in the order of the tree k_trace4 walks: p1, e1, e2, flat index
+  const float4 *tris2;                    // triangles in the reference's flat order (k_trace2)
   const uint2 *big;                       // (start, count) of leaves with more than 15 primitives
   const float4 *ray_o, *ray_d;
   const uint32_t *queue, *qcount;
@@ -61,6 +62,7 @@ struct TraceArgs {
   unsigned long long *redo_stat;          // counts rays re-traced by the reference walk (may be null)
   unsigned long long *count_stat;         // [0] node visits, [1] triangle tests (counting launches only)
   uint32_t count;
+  uint32_t require_unit;                  // traversal 0: rays whose ctor direction is not unit length go to k_trace2
 };
 
 hipError_t launch_init(const RenderArgs &a, hipStream_t st);
