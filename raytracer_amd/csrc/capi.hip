@@ -66,7 +66,7 @@ struct Global {
   float table[256];
   bool table_exact = false;
   DevBuf d_table;
-  uint32_t *h_counts = nullptr;          // pinned: RING x QC_COUNT
+  uint32_t *h_counts = nullptr;          // pinned: RING x QC_WORDS
   hipEvent_t ring_ev[RING] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> pool;          // timing events for profiled renders (recorded without host syncs)
@@ -83,24 +83,34 @@ struct Global {
 
 struct Timed { int kind; hipEvent_t a, b; };   // kind 0 logic, 1 closest trace, 2 shadow trace
 
-// control block layout (uint32): qcount[4] | work_head[2] | redo_count[2] | error flag
-enum { CTRL_QCOUNT = 0, CTRL_WORK = 4, CTRL_REDO = 6, CTRL_ERR = 8, CTRL_WORDS = 12 };
+// control block layout (uint32 words, every counter on a 128-byte line of its own, see kernels.hpp):
+// queue counters | fetch counters of the closest launch | of the shadow launch | redo counts | deferred-microfacet
+// count | error flag.  Everything before the error flag is cleared at the top of every iteration.
+enum {
+  CTRL_QCOUNT = 0,
+  CTRL_WORK = QC_WORDS,
+  CTRL_REDO = CTRL_WORK + 2 * WORK_PARTS * CTR_STRIDE,
+  CTRL_MF = CTRL_REDO + 2 * CTR_STRIDE,
+  CTRL_ERR = CTRL_MF + CTR_STRIDE,
+  CTRL_WORDS = CTRL_ERR + CTR_STRIDE
+};
 
 }  // namespace
 
 struct mirt_scene {
   HostBVH bvh;
   uint32_t n_tris = 0, n_mats = 0, n_lights = 0;
+  bool has_microfacet = false;
   DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big, nodes4f, trisf;
   uint32_t ovf_depth = 0;
   uint32_t trace_threads = 0;
   // work buffers (sized per render)
-  DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2];
+  DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2], mf_queue;
   DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t;
   size_t device_bytes() const {
     const DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &nodes4f, &trisf, &st, &mask, &total, &accum, &dmask,
                            &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0],
-                           &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t};
+                           &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue};
     size_t s = 0;
     for (auto *b: all) s += b->bytes;
     return s;
@@ -108,7 +118,7 @@ struct mirt_scene {
   void release_all() {
     DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &nodes4f, &trisf, &st, &mask, &total, &accum, &dmask,
                      &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0], &redo_q[1],
-                     &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t};
+                     &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue};
     for (auto *b: all) b->release();
   }
 };
@@ -133,7 +143,7 @@ int mirt_init(int device) {
   G.table_exact = build_tonemap_table(G.table);
   HIPCHK(G.d_table.ensure(sizeof(G.table)));
   HIPCHK(hipMemcpy(G.d_table.p, G.table, sizeof(G.table), hipMemcpyHostToDevice));
-  HIPCHK(hipHostMalloc((void **) &G.h_counts, RING * QC_COUNT * sizeof(uint32_t), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **) &G.h_counts, RING * QC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   for (int i = 0; i < RING; i++) HIPCHK(hipEventCreateWithFlags(&G.ring_ev[i], hipEventDisableTiming));
   HIPCHK(hipEventCreate(&G.ev0));
   HIPCHK(hipEventCreate(&G.ev1));
@@ -213,6 +223,12 @@ int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t
     for (uint32_t j = 0; j < n_tris; j++)
       memcpy(&trif[(size_t) j * 12], &tri[(size_t) s->bvh.fast_to_flat[j] * 12], 12 * sizeof(float));
   }
+  // materials: mirt_bsdf records (9 dwords) padded to three float4
+  std::vector<float> mats_padded((size_t) n_mats * 12, 0.f);
+  for (uint32_t m = 0; m < n_mats; m++) {
+    memcpy(&mats_padded[(size_t) m * 12], &mats[m], sizeof(mirt_bsdf));
+    if (mats[m].type == BSDF_MICROFACET) s->has_microfacet = true;
+  }
   int rc = MIRT_OK;
   auto up = [&](DevBuf &b, const void *src, size_t bytes) -> bool {
     if (b.ensure(bytes) != hipSuccess) return false;
@@ -223,7 +239,7 @@ int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t
             up(s->nodes2, s->bvh.nodes2.data(), s->bvh.nodes2.size() * sizeof(Node2)) &&
             up(s->nodes4f, s->bvh.nodes4f.data(), s->bvh.nodes4f.size() * sizeof(Node4)) &&
             up(s->trisf, trif.data(), trif.size() * 4) &&
-            up(s->mats, mats, (size_t) n_mats * sizeof(mirt_bsdf)) &&
+            up(s->mats, mats_padded.data(), mats_padded.size() * 4) &&
             up(s->big, s->bvh.big.empty() ? (const void *) mats : (const void *) s->bvh.big.data(), s->bvh.big.empty() ? 8 : s->bvh.big.size() * 4) &&
             up(s->lights, lights ? (const void *) lights : (const void *) mats, n_lights ? (size_t) n_lights * sizeof(mirt_light) : 4);
   if (ok) {
@@ -352,6 +368,7 @@ int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
   HIPCHK(s->sh_queue.ensure(kn * 4));
   HIPCHK(s->redo_q[0].ensure(n * 4));
   HIPCHK(s->redo_q[1].ensure(kn * 4));
+  HIPCHK(s->mf_queue.ensure(n * 4));
   HIPCHK(s->ctrl.ensure(CTRL_WORDS * 4));
   HIPCHK(s->ray_stats.ensure(8 * 8));
   return MIRT_OK;
@@ -402,11 +419,11 @@ TraceArgs shadow_args(mirt_scene *s, uint32_t traversal) {
   t.qc_front = QC_SHADOW;
   t.qc_back = -1;
   t.occ = s->sh_occ.as<uint32_t>();
-  t.work_head = ctrl + CTRL_WORK + 1;
+  t.work_head = ctrl + CTRL_WORK + WORK_PARTS * CTR_STRIDE;
   t.ovf = s->ovf.as<uint2>();
   t.ovf_depth = s->ovf_depth;
   t.redo_queue = s->redo_q[1].as<uint32_t>();
-  t.redo_count = ctrl + CTRL_REDO + 1;
+  t.redo_count = ctrl + CTRL_REDO + CTR_STRIDE;
   t.error_flag = ctrl + CTRL_ERR;
   t.redo_stat = s->ray_stats.as<unsigned long long>() + 3;
   t.count_stat = s->ray_stats.as<unsigned long long>() + 6;
@@ -482,7 +499,8 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   a.qcount = ctrl + CTRL_QCOUNT;
   a.ray_stats = s->ray_stats.as<unsigned long long>();
   a.out_accum = (float4 *) accum_dev;
-  a.tri_nrm = s->tri_nrm.as<float4>(); a.mats = s->mats.as<float>(); a.lights = s->lights.as<float>();
+  a.tri_nrm = s->tri_nrm.as<float4>(); a.mats = s->mats.as<float4>(); a.lights = s->lights.as<float>();
+  a.mf_queue = s->mf_queue.as<uint32_t>(); a.mf_count = ctrl + CTRL_MF;
 
   const bool profile = stats && (o.reserved[0] & 1u);
   const bool counting = stats && (o.reserved[0] & 2u);
@@ -499,6 +517,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   HIPCHK(hipMemsetAsync(s->ctrl.p, 0, CTRL_WORDS * 4, G.stream));
   HIPCHK(hipEventRecord(evA, G.stream));
   uint32_t iters = 0;
+  uint64_t n_camera = 0, n_bounced = 0, n_shadow_rays = 0;
   if (part.n_slots) {
     HIPCHK(launch_init(a, G.stream));
     const uint64_t max_iters = (uint64_t) a.spp * ((uint64_t) a.max_depth + 3) + 8;
@@ -517,13 +536,14 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
         if (!tl.a || !tl.b) return fail(MIRT_E_DEVICE, "could not create timing events");
         HIPCHK(hipEventRecord(tl.a, G.stream));
       }
-      HIPCHK(launch_logic(a, G.stream));
+      HIPCHK(launch_logic(a, false, G.stream));
+      if (s->has_microfacet) HIPCHK(launch_logic(a, true, G.stream));
       if (profile) {
         HIPCHK(hipEventRecord(tl.b, G.stream));
         timed.push_back(tl);
       }
       const int slot = (int) (it % RING);
-      HIPCHK(hipMemcpyAsync(G.h_counts + slot * QC_COUNT, ctrl + CTRL_QCOUNT, QC_COUNT * 4, hipMemcpyDeviceToHost, G.stream));
+      HIPCHK(hipMemcpyAsync(G.h_counts + slot * QC_WORDS, ctrl + CTRL_QCOUNT, QC_WORDS * 4, hipMemcpyDeviceToHost, G.stream));
       HIPCHK(hipEventRecord(G.ring_ev[slot], G.stream));
       rc = run_trace(s, tc, false, o.traversal, profile ? &timed : nullptr, counting);
       if (rc) return rc;
@@ -534,9 +554,14 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
       iters++;
       if (it + 1 >= RING - 1) {                                          // look at the counters of RING-2 iterations ago
         const uint64_t old = it + 1 - (RING - 1);
-        const int oslot = (int) (old % RING);
-        HIPCHK(hipEventSynchronize(G.ring_ev[oslot]));
-        if (G.h_counts[oslot * QC_COUNT + QC_ACTIVE] == 0) done = true;
+        const uint32_t *hc = G.h_counts + (old % RING) * QC_WORDS;
+        HIPCHK(hipEventSynchronize(G.ring_ev[old % RING]));
+        // a slot that is not finished leaves a ray in one of the queues: empty queues = frame complete (and every later
+        // iteration already launched found them empty too)
+        n_camera += hc[QC_EXT_FRONT];
+        n_bounced += hc[QC_EXT_BACK];
+        n_shadow_rays += hc[QC_SHADOW];
+        if (hc[QC_EXT_FRONT] + hc[QC_EXT_BACK] + hc[QC_SHADOW] == 0) done = true;
       }
     }
   }
@@ -559,9 +584,9 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     unsigned long long rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIPCHK(hipMemcpy(rs, s->ray_stats.p, 64, hipMemcpyDeviceToHost));
     memset(stats, 0, sizeof *stats);
-    stats->closest_rays = rs[0];
-    stats->shadow_rays = rs[1];
-    stats->paths = rs[2];
+    stats->closest_rays = n_camera + n_bounced;
+    stats->shadow_rays = n_shadow_rays;
+    stats->paths = n_camera;
     stats->exact_fallback_rays = rs[3];
     stats->iterations = iters;
     stats->tonemap_table_exact = G.table_exact ? 1 : 0;

@@ -73,21 +73,21 @@ struct PathCtx {
   uint32_t depth;
 };
 
-__device__ __forceinline__ void emit_extension(const RenderArgs &a, uint32_t s, const DRay &r, bool primary) {
+// What a slot appended this iteration; queue positions are handed out per workgroup at the end of k_logic.
+struct Emit {
+  uint32_t ext;        // 0 none, 1 camera ray (front of the extension queue), 2 bounced ray (back of the same array)
+  uint32_t nsh;        // shadow rays written to entries k * n_slots + s, k < nsh (0 or n_lights * spl)
+};
+
+__device__ __forceinline__ void emit_extension(const RenderArgs &a, uint32_t s, const DRay &r, bool primary, Emit &em) {
   a.ray_o[s] = make_float4(r.o.x, r.o.y, r.o.z, r.min_t);
   a.ray_d[s] = make_float4(r.d_arg.x, r.d_arg.y, r.d_arg.z, r.max_t);
-  if (primary) {
-    uint32_t pos = wave_reserve(a.qcount + QC_EXT_FRONT, 1);         // coherent camera rays: front of the queue
-    a.ext_queue[pos] = s;
-  } else {
-    uint32_t pos = wave_reserve(a.qcount + QC_EXT_BACK, 1);          // bounced rays: back of the same array
-    a.ext_queue[a.n_slots - 1 - pos] = s;
-  }
+  em.ext = primary ? 1u : 2u;
 }
 
 // raytracer.cuh:100-107: jittered film point -> camera ray.  `sample_index` only matters in counter mode.
 __device__ __forceinline__ void generate_camera_ray(const RenderArgs &a, uint32_t s, uint32_t px, uint32_t py,
-                                                    PathCtx &c, uint32_t sample_number) {
+                                                    PathCtx &c, uint32_t sample_number, Emit &em) {
   if (c.rng.mode == 1) {
     c.rng.state = 0;
     c.rng.sample = a.sample_begin + sample_number - 1;
@@ -96,13 +96,71 @@ __device__ __forceinline__ void generate_camera_ray(const RenderArgs &a, uint32_
   float gy = rng_next(c.rng);
   float fx = (float) px + gx, fy = (float) py + gy;
   DRay r = camera_generate_ray(a.cam, fx / (float) a.width, fy / (float) a.height, c.rng);
-  emit_extension(a, s, r, true);
+  emit_extension(a, s, r, true, em);
   c.depth = 0;
   c.flags |= F_HAS_RAY;
 }
 
-__device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s, const uint4 st, uint32_t &n_closest,
-                                           uint32_t &n_shadow_rays, uint32_t &n_paths) {
+// Tables every lane reads at the same address (lights) are read through the constant address space: scalar loads into
+// SGPRs instead of one VGPR per value and lane.
+typedef const float __attribute__((address_space(4))) *uniform_floats;
+
+// One slot, one iteration.  MF = false is the main kernel: it is compiled without the microfacet BSDF (whose double
+// precision pow/exp/tan/erf would set the register budget of every slot) and hands slots that hit such a material,
+// untouched, to the MF = true kernel through mf_queue.
+template<bool MF>
+__device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s, const uint4 st, Emit &em) {
+  const uint32_t flags0 = st.z & 0xFF;
+  uint32_t n_shadow = (st.z >> 8) & 0xFFFF;
+  const bool has_ray = (flags0 & F_HAS_RAY) != 0;
+
+  // ---- 0. every load this slot can need, issued in dependency order before anything waits on one of them
+  float4 h = make_float4(0, 0, 0, u2f(0xFFFFFFFFu));
+  if (has_ray) h = a.hit[s];
+  const float4 tot4 = a.total[s];
+  float4 acc4 = a.accum[s];
+  float4 m4 = make_float4(0, 0, 0, 0), ro = m4, rd = m4, dm = m4, sc0 = m4, sc1 = m4;
+  uint32_t occ0 = 1, occ1 = 1;
+  if (has_ray) {
+    m4 = a.mask[s];
+    ro = a.ray_o[s];
+    rd = a.ray_d[s];
+  }
+  if (n_shadow) {
+    dm = a.dmask[s];
+    occ0 = a.sh_occ[s];
+    sc0 = a.sh_c[s];
+    if (n_shadow > 1) {
+      occ1 = a.sh_occ[(size_t) a.n_slots + s];
+      sc1 = a.sh_c[(size_t) a.n_slots + s];
+    }
+  }
+  const int32_t prim = (int32_t) f2u(h.w);
+  const bool shade = has_ray && prim >= 0;
+  float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+  if (shade) {
+    n0 = a.tri_nrm[3 * (size_t) prim];
+    n1 = a.tri_nrm[3 * (size_t) prim + 1];
+    n2 = a.tri_nrm[3 * (size_t) prim + 2];
+  }
+  DBsdf bsdf;
+  bsdf.type = BSDF_DIFFUSE;
+#pragma unroll
+  for (int k = 0; k < 8; k++) bsdf.p[k] = 0.f;
+  if (shade) {
+    const float4 *mp = a.mats + 3 * (size_t) f2u(n2.y);
+    const float4 b0 = mp[0], b1 = mp[1], b2 = mp[2];
+    bsdf.type = (int32_t) f2u(b0.x);
+    bsdf.p[0] = b0.y; bsdf.p[1] = b0.z; bsdf.p[2] = b0.w;
+    bsdf.p[3] = b1.x; bsdf.p[4] = b1.y; bsdf.p[5] = b1.z; bsdf.p[6] = b1.w;
+    bsdf.p[7] = b2.x;
+  }
+  if (!MF && shade && bsdf.type == BSDF_MICROFACET) {
+    const uint32_t pos = wave_reserve(a.mf_count, 1);
+    a.mf_queue[pos] = s;
+    return;
+  }
+
   uint32_t px, py;
   bool valid;
   slot_to_pixel(a, s, px, py, valid);
@@ -112,21 +170,20 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
   c.rng.state = st.x;
   c.rng.key = (a.rng_mode == 1) ? ctr_key(py * a.width + px, a.seed) : 0;
   c.i = st.y;
-  c.flags = st.z & 0xFF;
+  c.flags = flags0;
   c.depth = st.w;
   // counter mode: the path in flight belongs to sample i, or to i + 1 when it was started ahead of the finalisation
   c.rng.sample = a.sample_begin + c.i + ((c.flags & F_AHEAD) ? 1u : 0u) - 1u;
-  uint32_t n_shadow = (st.z >> 8) & 0xFFFF;
 
-  float4 tot4 = a.total[s];
   V3 total = mk(tot4.x, tot4.y, tot4.z);
   float s1 = tot4.w;
 
   // ---- 1. fold the shadow rays emitted at the previous hit (raytracer.cuh:43-47, :68)
   if (n_shadow) {
-    float4 dm = a.dmask[s];
     V3 color = mk(0, 0, 0);
-    for (uint32_t k = 0; k < n_shadow; k++) {
+    if (occ0 == 0) color = vadd(color, mk(sc0.x, sc0.y, sc0.z));
+    if (n_shadow > 1 && occ1 == 0) color = vadd(color, mk(sc1.x, sc1.y, sc1.z));
+    for (uint32_t k = 2; k < n_shadow; k++) {
       size_t e = (size_t) k * a.n_slots + s;
       if (a.sh_occ[e] == 0) {
         float4 cc = a.sh_c[e];
@@ -137,13 +194,13 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
     n_shadow = 0;
   }
 
-  float4 acc4 = a.accum[s];
-  bool finished = false;
+  bool finished = false, acc_dirty = false;
   float divisor = 0.f;
 
   // finish sample c.i: raytracer.cuh:111-122
   auto finalize = [&]() {
     acc4.x += total.x; acc4.y += total.y; acc4.z += total.z;
+    acc_dirty = true;
     float illum = villum(total);
     s1 += illum;
     total = mk(0, 0, 0);
@@ -175,40 +232,24 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
   if (!finished) {
     if (!(c.flags & F_HAS_RAY)) {
       // ---- first sample of the pixel
-      n_paths++;
-      n_closest++;
       a.mask[s] = make_float4(1, 1, 1, 0);
-      generate_camera_ray(a, s, px, py, c, c.i);
+      generate_camera_ray(a, s, px, py, c, c.i, em);
     } else {
       // ---- 3. the extension ray of this path was traced: shade (estimate_global_lighting body, raytracer.cuh:60-88)
-      float4 h = a.hit[s];
-      const int32_t prim = (int32_t) f2u(h.w);
-      float4 m4 = a.mask[s];
       V3 mask = mk(m4.x, m4.y, m4.z);
       bool path_ends = false;
       DRay next;
       if (prim < 0) {
         path_ends = true;                                   // miss: break (raytracer.cuh:62)
       } else {
-        const float4 ro = a.ray_o[s], rd = a.ray_d[s];
         const V3 origin = mk(ro.x, ro.y, ro.z);
         const V3 direction = vunit(mk(rd.x, rd.y, rd.z));   // Ray::direction (ray.cuh:20)
-        const float4 n0 = a.tri_nrm[3 * (size_t) prim], n1 = a.tri_nrm[3 * (size_t) prim + 1],
-                     n2 = a.tri_nrm[3 * (size_t) prim + 2];
-        const uint32_t mat = f2u(n2.y);
         const float by = h.y, bz = h.z;
         const float bx = 1 - by - bz;                       // primitives.cuh:147
         DIsect is;
         is.normal = vadd(vadd(vlscale(bx, mk(n0.x, n0.y, n0.z)), vlscale(by, mk(n0.w, n1.x, n1.y))),
                          vlscale(bz, mk(n1.z, n1.w, n2.x)));           // primitives.cuh:156
         isect_compute(is, origin, direction, h.x);
-        DBsdf bsdf;
-        {
-          const float *mp = a.mats + 9 * (size_t) mat;
-          bsdf.type = (int32_t) f2u(mp[0]);
-#pragma unroll
-          for (int k = 0; k < 8; k++) bsdf.p[k] = mp[1 + k];
-        }
         if (bsdf.type == BSDF_EMISSION) total = vadd(total, vmul(mask, mk(bsdf.p[0], bsdf.p[1], bsdf.p[2])));
         else total = vadd(total, vmul(mask, mk(0, 0, 0)));  // raytracer.cuh:65 (keeps inf/NaN * 0 semantics)
 
@@ -220,7 +261,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
           for (uint32_t li = 0; li < a.n_lights; li++) {
             DLight L;
             {
-              const float *lp = a.lights + 17 * (size_t) li;
+              uniform_floats lp = (uniform_floats) a.lights + 17 * (size_t) li;
               L.type = (int32_t) f2u(lp[0]);
 #pragma unroll
               for (int q = 0; q < 16; q++) L.p[q] = lp[1 + q];
@@ -229,7 +270,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
               V3 to_light;
               float dist, pdf;
               V3 Lr = light_sample(L, so, to_light, dist, pdf, c.rng);
-              V3 f = bsdf_f(bsdf, is.o_out, mmulv(is.w2o, to_light));
+              V3 f = bsdf_f<MF>(bsdf, is.o_out, mmulv(is.w2o, to_light));
               V3 sdir = vunit(to_light);                                // shadow_ray.direction
               float cosv = smax(vdot(is.normal, vunit(sdir)), 0.f);     // raytracer.cuh:45
               V3 contrib = vdiv(vdiv(vscale(vmul(f, Lr), cosv), pdf), (float) a.spl);
@@ -237,12 +278,10 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
               a.sh_o[e] = make_float4(so.x, so.y, so.z, MIRT_EPS);
               a.sh_d[e] = make_float4(to_light.x, to_light.y, to_light.z, dist - MIRT_EPS);
               a.sh_c[e] = make_float4(contrib.x, contrib.y, contrib.z, 0);
-              uint32_t pos = wave_reserve(a.qcount + QC_SHADOW, 1);
-              a.sh_queue[pos] = (uint32_t) e;
             }
           }
           n_shadow = k;
-          n_shadow_rays += k;
+          em.nsh = k;
           a.dmask[s] = make_float4(mask.x, mask.y, mask.z, 0);
         }
 
@@ -252,7 +291,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
         } else {
           float pdf;
           V3 bmask;
-          V3 o_in = bsdf_sample(bsdf, is.o_out, bmask, pdf, c.rng, a.glass_int_abs != 0);
+          V3 o_in = bsdf_sample<MF>(bsdf, is.o_out, bmask, pdf, c.rng, a.glass_int_abs != 0);
           if (pdf == 0) {
             path_ends = true;                                           // :79
           } else {
@@ -271,8 +310,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
 
       if (!path_ends) {
         a.mask[s] = make_float4(mask.x, mask.y, mask.z, 0);
-        emit_extension(a, s, next, false);
-        n_closest++;
+        emit_extension(a, s, next, false, em);
       } else {
         c.flags &= ~F_HAS_RAY;
         if (n_shadow > 0) {
@@ -281,18 +319,14 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
           c.flags |= F_PENDING;
           if (c.i + 1 <= a.spp) {
             c.flags |= F_AHEAD;
-            n_paths++;
-            n_closest++;
             a.mask[s] = make_float4(1, 1, 1, 0);
-            generate_camera_ray(a, s, px, py, c, c.i + 1);
+            generate_camera_ray(a, s, px, py, c, c.i + 1, em);
           }
         } else {
           finalize();
           if (!finished) {
-            n_paths++;
-            n_closest++;
             a.mask[s] = make_float4(1, 1, 1, 0);
-            generate_camera_ray(a, s, px, py, c, c.i);
+            generate_camera_ray(a, s, px, py, c, c.i, em);
           }
         }
       }
@@ -303,39 +337,58 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
     c.flags = F_DONE;
     n_shadow = 0;
     a.out_accum[(size_t) py * a.width + px] = make_float4(acc4.x, acc4.y, acc4.z, divisor);
-  } else {
-    uint64_t m = __ballot(1);
-    if (lane_rank(m) == 0) atomicAdd(a.qcount + QC_ACTIVE, (uint32_t) __popcll(m));
   }
   a.total[s] = make_float4(total.x, total.y, total.z, s1);
-  a.accum[s] = acc4;
+  if (acc_dirty) a.accum[s] = acc4;
   a.st[s] = make_uint4(c.rng.state, c.i, c.flags | (n_shadow << 8), c.depth);
-
 }
 
+// MF = false: one thread per slot.  MF = true: workgroup-stride over the slots the main kernel deferred.
+// Queue positions are reserved once per workgroup and queue (three atomics, each on a line of its own): a slot that is
+// not finished always leaves a ray in one of the queues, so the queue counters double as the "anything left?" test and
+// as the ray statistics (the host adds them up per iteration).
+template<bool MF>
 __global__ void __launch_bounds__(256) k_logic(RenderArgs a) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t n_closest = 0, n_shadow_rays = 0, n_paths = 0;
-  if (s < a.n_slots) {
-    const uint4 st = a.st[s];
-    if (!(st.z & F_DONE)) logic_slot(a, s, st, n_closest, n_shadow_rays, n_paths);
-  }
-  // ray statistics: every lane of the wave takes part in the reduction (finished slots contribute zeros); one atomic per
-  // wave and counter
-  {
-    uint32_t v0 = n_closest, v1 = n_shadow_rays, v2 = n_paths;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      v0 += __shfl_xor(v0, o);
-      v1 += __shfl_xor(v1, o);
-      v2 += __shfl_xor(v2, o);
+  __shared__ uint32_t wave_cnt[4][3];
+  __shared__ uint32_t block_base[3], block_tot[3];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6;
+  const uint32_t n = MF ? *a.mf_count : a.n_slots;
+  const uint32_t K = a.n_lights * a.spl;
+  for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
+    const uint32_t i = base + tid;
+    uint32_t s = 0;
+    Emit em;
+    em.ext = 0; em.nsh = 0;
+    if (i < n) {
+      s = MF ? a.mf_queue[i] : i;
+      const uint4 st = a.st[s];
+      if (MF || !(st.z & F_DONE)) logic_slot<MF>(a, s, st, em);
     }
-    const uint64_t m = __ballot(1);
-    if (lane_rank(m) == 0) {
-      if (v0) atomicAdd((unsigned long long *) a.ray_stats + 0, (unsigned long long) v0);
-      if (v1) atomicAdd((unsigned long long *) a.ray_stats + 1, (unsigned long long) v1);
-      if (v2) atomicAdd((unsigned long long *) a.ray_stats + 2, (unsigned long long) v2);
+    const uint64_t m0 = __ballot(em.ext == 1), m1 = __ballot(em.ext == 2), m2 = __ballot(em.nsh != 0);
+    if ((tid & 63) == 0) {
+      wave_cnt[wave][0] = (uint32_t) __popcll(m0);
+      wave_cnt[wave][1] = (uint32_t) __popcll(m1);
+      wave_cnt[wave][2] = (uint32_t) __popcll(m2);
     }
+    __syncthreads();
+    if (tid < 3) {
+      const uint32_t tot = wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
+      block_tot[tid] = tot;
+      block_base[tid] = tot ? atomicAdd(a.qcount + CTR_STRIDE * tid, tid == 2 ? tot * K : tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t off[3] = {0, 0, 0};
+    for (uint32_t w = 0; w < wave; w++) {
+      off[0] += wave_cnt[w][0]; off[1] += wave_cnt[w][1]; off[2] += wave_cnt[w][2];
+    }
+    if (em.ext == 1) a.ext_queue[block_base[0] + off[0] + lane_rank(m0)] = s;                     // camera rays: front
+    if (em.ext == 2) a.ext_queue[a.n_slots - 1 - (block_base[1] + off[1] + lane_rank(m1))] = s;   // bounced rays: back
+    if (em.nsh) {
+      // light-major inside the workgroup's range: consecutive entries go to the same light from neighbouring pixels
+      const uint32_t p = block_base[2] + off[2] + lane_rank(m2);
+      for (uint32_t k = 0; k < K; k++) a.sh_queue[p + k * block_tot[2]] = k * a.n_slots + s;
+    }
+    __syncthreads();
   }
 }
 
@@ -489,8 +542,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
   LaneRay r;
   r.id = 0; r.best_idx = -1; r.best_t = 0; r.min_t = 0; r.b1 = r.b2 = 0;
   r.o = r.d = r.inv = mk(0, 0, 0);
-  bool active = false, exhausted = false;
+  bool active = false;
   uint32_t cur = CHILD_EMPTY;
+  // wave-uniform fetch state
+  const uint32_t psz = ((total + WORK_PARTS - 1) / WORK_PARTS + 63u) & ~63u;        // queue positions per range
+  uint32_t chunk = (total / (gridDim.x * (TRACE_BLOCK / 64) * 4u)) & ~31u;          // ~4 chunks per wave
+  chunk = chunk < 32u ? 32u : (chunk > 256u ? 256u : chunk);
+  uint32_t w_next = 0, w_end = 0, part = blockIdx.x & (WORK_PARTS - 1), parts_tried = 0;
+  bool wave_done = (total == 0);
   int sp = 0;
   uint32_t n_nodes = 0, n_tris = 0;
 
@@ -510,39 +569,64 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
   };
 
   while (true) {
-    // ---------------------------------------------------------------- dynamic fetch: one atomic per wave
-    if (!active && !exhausted) {
-      const uint32_t w = wave_reserve(a.work_head, 1);
-      if (w < total) {
-        const uint32_t id = (w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)];
-        load_ray(a, id, r);
-        // Slab and hit arithmetic stays finite for these rays; anything else (zero direction components -> 0 * inf,
-        // non-finite origins, NaN bounds) makes the reference's result depend on its visiting order: defer to k_trace2.
-        bool regular = finite3(r.o) && finite3(r.d) && finite3(r.inv) && (r.best_t == r.best_t) &&
-                       (r.min_t == r.min_t);
-        if (a.require_unit) {
-          // The reference prunes boxes with t measured along the UN-normalised ctor direction but hits with t along the
-          // normalised one (ray.cuh:19-21): unless the two agree (the integrator only makes unit directions) its result
-          // depends on its own boxes and visiting order, so such rays take the reference walk (traversal 0 only: its
-          // tree is not the reference's).
-          const float4 rd = a.ray_d[id];
-          const float l2 = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
-          regular = regular && (fabsf(l2 - 1.0f) < 1e-4f);
+    // ---------------------------------------------------------------- dynamic fetch
+    // Idle lanes take the next queue positions of the wave's private range [w_next, w_end); the wave refills that range
+    // a chunk at a time from one of WORK_PARTS counters (its home range first, then the others): few atomics, spread
+    // over several lines.
+    const uint64_t need = __ballot(!active);
+    if (need != 0 && !wave_done) {
+      if (w_next >= w_end) {
+        while (parts_tried < (uint32_t) WORK_PARTS) {
+          uint32_t got = 0;
+          if ((tid & 63) == 0) got = atomicAdd(a.work_head + CTR_STRIDE * part, chunk);
+          got = __builtin_amdgcn_readfirstlane(got);
+          const uint32_t lo = part * psz + got;
+          if (got < psz && lo < total) {
+            const uint32_t hi_part = (part + 1) * psz < total ? (part + 1) * psz : total;
+            w_next = lo;
+            w_end = lo + chunk < hi_part ? lo + chunk : hi_part;
+            break;
+          }
+          part = (part + 1) & (WORK_PARTS - 1);
+          parts_tried++;
         }
-        if (regular) {
-          active = true;
-          cur = 0;
-          sp = 0;
-        } else {
-          const uint32_t pos = wave_reserve(a.redo_count, 1);
-          a.redo_queue[pos] = id;
+        if (w_next >= w_end) wave_done = true;
+      }
+      if (!wave_done) {
+        if (!active) {
+          const uint32_t w = w_next + lane_rank(need);
+          if (w < w_end) {
+            const uint32_t id = (w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)];
+            load_ray(a, id, r);
+            // Slab and hit arithmetic stays finite for these rays; anything else (zero direction components -> 0 * inf,
+            // non-finite origins, NaN bounds) makes the reference's result depend on its visiting order: defer to k_trace2.
+            bool regular = finite3(r.o) && finite3(r.d) && finite3(r.inv) && (r.best_t == r.best_t) &&
+                           (r.min_t == r.min_t);
+            if (a.require_unit) {
+              // The reference prunes boxes with t measured along the UN-normalised ctor direction but hits with t along
+              // the normalised one (ray.cuh:19-21): unless the two agree (the integrator only makes unit directions) its
+              // result depends on its own boxes and visiting order, so such rays take the reference walk (traversal 0
+              // only: its tree is not the reference's).
+              const float4 rd = a.ray_d[id];
+              const float l2 = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
+              regular = regular && (fabsf(l2 - 1.0f) < 1e-4f);
+            }
+            if (regular) {
+              active = true;
+              cur = 0;
+              sp = 0;
+            } else {
+              const uint32_t pos = wave_reserve(a.redo_count, 1);
+              a.redo_queue[pos] = id;
+            }
+          }
         }
-      } else {
-        exhausted = true;
+        const uint32_t taken = (uint32_t) __popcll(need);
+        w_next = (w_end - w_next) < taken ? w_end : w_next + taken;
       }
     }
     if (!__any(active)) {
-      if (__all(exhausted)) break;
+      if (wave_done) break;
       continue;
     }
 
@@ -677,7 +761,11 @@ __global__ void k_probe_primary(RenderArgs a) {
   c.rng.key = (a.rng_mode == 1) ? ctr_key(py * a.width + px, a.seed) : 0;
   c.rng.sample = 0;
   c.i = 1; c.flags = 0; c.depth = 0;
-  generate_camera_ray(a, s, px, py, c, 1);
+  Emit em;
+  em.ext = 0; em.nsh = 0;
+  generate_camera_ray(a, s, px, py, c, 1, em);
+  const uint32_t pos = wave_reserve(a.qcount + QC_EXT_FRONT, 1);
+  a.ext_queue[pos] = s;
 }
 
 __global__ void k_gather_primary(RenderArgs a, int32_t *idx_out, uint32_t *tbits_out) {
@@ -733,8 +821,13 @@ hipError_t launch_init(const RenderArgs &a, hipStream_t st) {
   LAUNCH_CHECK();
   return hipSuccess;
 }
-hipError_t launch_logic(const RenderArgs &a, hipStream_t st) {
-  k_logic<<<(a.n_slots + 255) / 256, 256, 0, st>>>(a);
+hipError_t launch_logic(const RenderArgs &a, bool deferred_microfacet, hipStream_t st) {
+  if (!deferred_microfacet) {
+    k_logic<false><<<(a.n_slots + 255) / 256, 256, 0, st>>>(a);
+  } else {
+    const uint32_t blocks = (a.n_slots + 255) / 256;
+    k_logic<true><<<blocks < 2048 ? blocks : 2048, 256, 0, st>>>(a);
+  }
   LAUNCH_CHECK();
   return hipSuccess;
 }

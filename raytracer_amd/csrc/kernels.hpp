@@ -14,8 +14,12 @@ constexpr int BVH2_STACK = 64;       // k_trace2 (the reference uses 32 unchecke
 
 // per-slot flag bits (RenderArgs::st[].z low byte)
 enum : uint32_t { F_DONE = 1, F_HAS_RAY = 2, F_PENDING = 4, F_AHEAD = 8 };
-// queue counters (RenderArgs::qcount)
-enum : int { QC_EXT_FRONT = 0, QC_EXT_BACK = 1, QC_SHADOW = 2, QC_ACTIVE = 3, QC_COUNT = 4 };
+// Queue counters (word offsets into RenderArgs::qcount).  Every counter that kernels update with atomics lives on a
+// 128-byte line of its own: same-address atomics retire at ~11 ns each on MI355X (tools/micro/atomic_rate.hip) and
+// counters sharing a line queue up behind each other.
+constexpr int CTR_STRIDE = 32;
+enum : int { QC_EXT_FRONT = 0, QC_EXT_BACK = CTR_STRIDE, QC_SHADOW = 2 * CTR_STRIDE, QC_WORDS = 3 * CTR_STRIDE };
+constexpr int WORK_PARTS = 8;        // a trace launch splits its queue into this many ranges, one fetch counter each
 
 struct RenderArgs {
   uint32_t n_slots, width, height, tiles_x, tiles_y, tile_rank, tile_world;
@@ -36,7 +40,8 @@ struct RenderArgs {
   unsigned long long *ray_stats;          // closest, shadow, paths
   float4 *out_accum;                      // width * height, (sum rgb, divisor)
   const float4 *tri_nrm;                  // 3 float4 per triangle: n1 n2 n3, material, original index
-  const float *mats;                      // 9 dwords per material (mirt_bsdf)
+  const float4 *mats;                     // 3 float4 per material: mirt_bsdf (9 dwords) padded to 48 B
+  uint32_t *mf_queue, *mf_count;          // slots whose hit material is MICROFACET: shaded by k_logic<true>
   const float *lights;                    // 17 dwords per light (mirt_light)
 };
 
@@ -53,7 +58,7 @@ struct TraceArgs {
   float4 *hit;                            // closest-hit output
   uint32_t *occ;                          // any-hit output
   float *any_t;                           // any-hit: max_t after the walk (probe only, may be null)
-  uint32_t *work_head;
+  uint32_t *work_head;                    // WORK_PARTS counters, CTR_STRIDE words apart
   uint2 *ovf;
   uint32_t ovf_depth;
   uint32_t *redo_queue, *redo_count;
@@ -66,7 +71,7 @@ struct TraceArgs {
 };
 
 hipError_t launch_init(const RenderArgs &a, hipStream_t st);
-hipError_t launch_logic(const RenderArgs &a, hipStream_t st);
+hipError_t launch_logic(const RenderArgs &a, bool deferred_microfacet, hipStream_t st);
 hipError_t launch_probe_primary(const RenderArgs &a, hipStream_t st);
 hipError_t launch_gather_primary(const RenderArgs &a, int32_t *idx, uint32_t *tb, hipStream_t st);
 hipError_t launch_iota(uint32_t *q, uint32_t n, hipStream_t st);

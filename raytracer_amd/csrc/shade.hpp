@@ -102,9 +102,11 @@ __device__ __noinline__ V3 microfacet_f(const DBsdf &b, V3 o_out, V3 o_in) {    
   V3 r = vscale(vscale(F, (float) G), (float) D);
   return vdiv(r, 4 * o_out.z * o_in.z);
 }
+// MF = false: instantiation for kernels that never see a MICROFACET material (k_logic<false> defers those slots)
+template<bool MF>
 __device__ __forceinline__ V3 bsdf_f(const DBsdf &b, V3 o_out, V3 o_in) {                             // :152-169
   if (b.type == BSDF_DIFFUSE) return vdiv(mk(b.p[0], b.p[1], b.p[2]), MIRT_PI);
-  if (b.type == BSDF_MICROFACET) return microfacet_f(b, o_out, o_in);
+  if (MF && b.type == BSDF_MICROFACET) return microfacet_f(b, o_out, o_in);
   return mk(0, 0, 0);
 }
 __device__ __forceinline__ bool bsdf_refract(V3 wo, V3 &wi, float ior) {                              // :292-307
@@ -133,6 +135,7 @@ __device__ __noinline__ V3 microfacet_sample(const DBsdf &b, V3 o_out, V3 &mask,
   mask = microfacet_f(b, o_out, o_in);
   return o_in;
 }
+template<bool MF>
 __device__ __forceinline__ V3 bsdf_sample(const DBsdf &b, V3 o_out, V3 &mask, float &pdf, Rng &seed,
                                           bool glass_int_abs) {                                      // :171-251
   float cos_o_out = o_out.z;
@@ -178,7 +181,10 @@ __device__ __forceinline__ V3 bsdf_sample(const DBsdf &b, V3 o_out, V3 &mask, fl
       float r0 = (float) ((double) q * (double) q);                    // pow(x, 2) in double is the exact square
       double base = glass_int_abs ? (double) (1 - abs((int) o_out.z))  // bsdf.cuh:213 under g++
                                   : (double) (1 - fabsf(o_out.z));     // under nvcc: float abs
-      float r = (float) ((double) r0 + (double) (1 - r0) * pow(base, 5.0));
+      // pow(base, 5.0) by multiplication: three double roundings, invisible after the conversion to float except in
+      // ~1e-8 of the cases (the device pow is not the host's correctly rounded one either); no double pow in this kernel
+      const double base2 = base * base;
+      float r = (float) ((double) r0 + (double) (1 - r0) * (base2 * base2 * base));
       if (rng_next(seed) < r) {
         o_in = mk(-o_out.x, -o_out.y, o_out.z);
         pdf = r * o_in.z;
@@ -191,7 +197,10 @@ __device__ __forceinline__ V3 bsdf_sample(const DBsdf &b, V3 o_out, V3 &mask, fl
       return o_in;
     }
     case BSDF_MICROFACET:
-      return microfacet_sample(b, o_out, mask, pdf, seed);
+      if (MF) return microfacet_sample(b, o_out, mask, pdf, seed);
+      pdf = 0;
+      mask = mk(0, 0, 0);
+      return mk(0, 0, 1);
     default:
       pdf = 0;
       mask = mk(0, 0, 0);
