@@ -63,6 +63,8 @@ struct Global {
   int n_cu = 0;
   int blocks_per_cu = 2;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;            // runs the closest-hit redo pass next to the shadow launch of the main stream
+  hipEvent_t fork_ev[RING] = {}, join_ev[RING] = {};
   float table[256];
   bool table_exact = false;
   DevBuf d_table;
@@ -144,7 +146,12 @@ int mirt_init(int device) {
   HIPCHK(G.d_table.ensure(sizeof(G.table)));
   HIPCHK(hipMemcpy(G.d_table.p, G.table, sizeof(G.table), hipMemcpyHostToDevice));
   HIPCHK(hipHostMalloc((void **) &G.h_counts, RING * QC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-  for (int i = 0; i < RING; i++) HIPCHK(hipEventCreateWithFlags(&G.ring_ev[i], hipEventDisableTiming));
+  HIPCHK(hipStreamCreateWithFlags(&G.side, hipStreamNonBlocking));
+  for (int i = 0; i < RING; i++) {
+    HIPCHK(hipEventCreateWithFlags(&G.ring_ev[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&G.fork_ev[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&G.join_ev[i], hipEventDisableTiming));
+  }
   HIPCHK(hipEventCreate(&G.ev0));
   HIPCHK(hipEventCreate(&G.ev1));
   G.blocks_per_cu = trace4_blocks_per_cu();
@@ -160,7 +167,13 @@ int mirt_init(int device) {
 void mirt_shutdown(void) {
   if (!G.ready) return;
   (void) hipStreamSynchronize(G.stream);
-  for (int i = 0; i < RING; i++) if (G.ring_ev[i]) (void) hipEventDestroy(G.ring_ev[i]);
+  if (G.side) (void) hipStreamSynchronize(G.side);
+  for (int i = 0; i < RING; i++) {
+    if (G.ring_ev[i]) (void) hipEventDestroy(G.ring_ev[i]);
+    if (G.fork_ev[i]) (void) hipEventDestroy(G.fork_ev[i]);
+    if (G.join_ev[i]) (void) hipEventDestroy(G.join_ev[i]);
+  }
+  if (G.side) (void) hipStreamDestroy(G.side);
   if (G.ev0) (void) hipEventDestroy(G.ev0);
   if (G.ev1) (void) hipEventDestroy(G.ev1);
   if (G.h_counts) (void) hipHostFree(G.h_counts);
@@ -430,7 +443,11 @@ TraceArgs shadow_args(mirt_scene *s, uint32_t traversal) {
   return t;
 }
 
-int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, std::vector<Timed> *timed, bool count = false) {
+// One trace launch plus the reference walk over the rays it set aside.  With `fork_slot >= 0` the redo pass runs on the
+// side stream (it is a handful of rays walking serially: latency, not throughput) and the caller joins
+// G.join_ev[fork_slot] into the main stream before anything reads the results.
+int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, std::vector<Timed> *timed, bool count = false,
+              int fork_slot = -1) {
   const uint32_t grid = s->trace_threads / TRACE_BLOCK;
   Timed tm{any ? 2 : 1, nullptr, nullptr};
   if (timed) {
@@ -447,7 +464,14 @@ int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, std::vec
   }
   if (traversal != 2) {
     t.redo = 1;
-    HIPCHK(launch_trace(t, any, 2, 256, G.stream));
+    if (fork_slot >= 0) {
+      HIPCHK(hipEventRecord(G.fork_ev[fork_slot], G.stream));
+      HIPCHK(hipStreamWaitEvent(G.side, G.fork_ev[fork_slot], 0));
+      HIPCHK(launch_trace(t, any, 2, 256, G.side));
+      HIPCHK(hipEventRecord(G.join_ev[fork_slot], G.side));
+    } else {
+      HIPCHK(launch_trace(t, any, 2, 256, G.stream));
+    }
   }
   return MIRT_OK;
 }
@@ -545,12 +569,14 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
       const int slot = (int) (it % RING);
       HIPCHK(hipMemcpyAsync(G.h_counts + slot * QC_WORDS, ctrl + CTRL_QCOUNT, QC_WORDS * 4, hipMemcpyDeviceToHost, G.stream));
       HIPCHK(hipEventRecord(G.ring_ev[slot], G.stream));
-      rc = run_trace(s, tc, false, o.traversal, profile ? &timed : nullptr, counting);
+      const bool fork = K != 0 && o.traversal != 2;
+      rc = run_trace(s, tc, false, o.traversal, profile ? &timed : nullptr, counting, fork ? slot : -1);
       if (rc) return rc;
       if (K) {
         rc = run_trace(s, ts, true, o.traversal, profile ? &timed : nullptr, counting);
         if (rc) return rc;
       }
+      if (fork) HIPCHK(hipStreamWaitEvent(G.stream, G.join_ev[slot], 0));
       iters++;
       if (it + 1 >= RING - 1) {                                          // look at the counters of RING-2 iterations ago
         const uint64_t old = it + 1 - (RING - 1);
