@@ -521,6 +521,77 @@ __global__ void __launch_bounds__(256) k_trace2(TraceArgs a) {
   }
 }
 
+// -------------------------------------------------------------------------------------------- k_redo (reference walk, one wave per ray)
+// The rays k_trace4 sets aside are few (edge hits, coplanar faces, non-finite arithmetic: ~2e-5 of all rays) but each is a
+// long, strictly ordered walk; per lane that is hundreds of dependent memory round trips.  Here a whole wave walks one
+// ray: the node walk is uniform (every lane reads the same node), and the triangles of a leaf are evaluated by 64 lanes
+// at once; the reference's sequential accept rule (primitives.cuh:149-152 inside bvh.cuh:62-72) is then replayed over
+// the candidates in index order, which is all the order dependence there is.
+template<bool ANY>
+__global__ void __launch_bounds__(256) k_redo(TraceArgs a) {
+  __shared__ uint32_t stack_lds[4][BVH2_STACK];
+  const uint32_t total = *a.redo_count;
+  const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+  const uint32_t wave = blockIdx.x * 4 + wave_in_block, n_waves = gridDim.x * 4;
+  uint32_t *stack = stack_lds[wave_in_block];
+  if (a.redo_stat && total && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.redo_stat, (unsigned long long) total);
+  for (uint32_t w = wave; w < total; w += n_waves) {
+    const uint32_t id = a.redo_queue[w];
+    LaneRay r;
+    load_ray(a, id, r);
+    uint32_t sp = 0;
+    stack[sp++] = 0;
+    bool found = false;
+    while (sp) {
+      const float4 *np = a.nodes2 + 2 * (size_t) stack[--sp];
+      const float4 n0 = np[0], n1 = np[1];
+      const float lo[3] = {n0.x, n0.y, n0.z}, hi[3] = {n0.w, n1.x, n1.y};
+      const uint32_t w0 = f2u(n1.z), w1 = f2u(n1.w);
+      if (!slab_exact(lo, hi, r, r.best_t)) continue;
+      if (w0 & 0x80000000u) {
+        const uint32_t cnt = w0 & 0x7fffffffu;
+        for (uint32_t base = 0; base < cnt && !found; base += 64) {
+          float t = 0, by = 0, bz = 0;
+          uint32_t flat;
+          bool cand = false;
+          if (base + lane < cnt) cand = tri_test(a.tris2, w1 + base + lane, r, MIRT_INF, t, by, bz, flat);   // all but `t > max_t`
+          uint64_t m = __ballot(cand);
+          int winner = -1;
+          while (m) {
+            const int l = (int) __builtin_ctzll(m);
+            m &= m - 1;
+            const float tl = __shfl(t, l);
+            if (!(tl > r.best_t)) {
+              r.best_t = tl;
+              winner = l;
+              if (ANY) { found = true; break; }
+            }
+          }
+          if (winner >= 0) {
+            r.b1 = __shfl(by, winner);
+            r.b2 = __shfl(bz, winner);
+            r.best_idx = (int32_t) (w1 + base + (uint32_t) winner);
+          }
+        }
+        if (ANY && found) break;
+      } else if (sp + 2 <= BVH2_STACK) {
+        stack[sp++] = w0;
+        stack[sp++] = w1;
+      } else {
+        atomicOr(a.error_flag, 1u);
+      }
+    }
+    if (lane == 0) {
+      if (ANY) {
+        a.occ[id] = found ? 1u : 0u;
+        if (a.any_t) a.any_t[id] = r.best_t;
+      } else {
+        a.hit[id] = make_float4(r.best_t, r.b1, r.b2, u2f((uint32_t) r.best_idx));
+      }
+    }
+  }
+}
+
 // -------------------------------------------------------------------------------------------- k_trace4 (wide BVH)
 // MODE 0: its own (SAH) tree, children sorted near-to-far.  The nearest hit does not depend on the tree or the order unless
 //         two candidates (or a candidate and the ray's t limits) lie within NEAR of each other; those rays are re-traced
@@ -864,7 +935,10 @@ int trace4_blocks_per_cu() {
 
 // traversal: 0 ordered wide, 1 DFS-order wide, 2 reference BVH2.  `a.redo` selects the deferred-ray pass of k_trace2.
 hipError_t launch_trace(const TraceArgs &a, bool any, uint32_t traversal, uint32_t grid_blocks, hipStream_t st) {
-  if (a.redo || traversal == 2) {
+  if (a.redo) {
+    if (any) k_redo<true><<<grid_blocks, 256, 0, st>>>(a);
+    else k_redo<false><<<grid_blocks, 256, 0, st>>>(a);
+  } else if (traversal == 2) {
     if (any) k_trace2<true><<<grid_blocks, 256, 0, st>>>(a);
     else k_trace2<false><<<grid_blocks, 256, 0, st>>>(a);
   } else {
