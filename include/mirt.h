@@ -94,6 +94,8 @@ typedef struct mirt_stats {
   uint32_t closest_launches, shadow_launches;         /* launches of the wide-BVH traversal kernel that were timed */
   uint64_t closest_node_visits, closest_tri_tests;    /* wide nodes fetched / triangles tested by closest-hit rays */
   uint64_t shadow_node_visits, shadow_tri_tests;
+  /* wave-level loop steps behind those counts: visits / (64 * steps) = SIMD lane utilisation of that loop */
+  uint64_t closest_node_steps, closest_tri_steps, shadow_node_steps, shadow_tri_steps;
 } mirt_stats;
 
 typedef struct mirt_scene mirt_scene;

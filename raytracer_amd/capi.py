@@ -54,7 +54,9 @@ class Stats(C.Structure):
                 ("render_ms", C.c_double), ("trace_closest_ms", C.c_double), ("trace_shadow_ms", C.c_double),
                 ("logic_ms", C.c_double), ("total_ms", C.c_double), ("closest_launches", C.c_uint32),
                 ("shadow_launches", C.c_uint32), ("closest_node_visits", C.c_uint64), ("closest_tri_tests", C.c_uint64),
-                ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64)]
+                ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
+                ("closest_node_steps", C.c_uint64), ("closest_tri_steps", C.c_uint64),
+                ("shadow_node_steps", C.c_uint64), ("shadow_tri_steps", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

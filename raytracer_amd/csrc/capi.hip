@@ -62,6 +62,7 @@ struct Global {
   int device = -1;
   int n_cu = 0;
   int blocks_per_cu = 2;
+  uint32_t min_lanes = 16;
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;            // runs the closest-hit redo pass next to the shadow launch of the main stream
   hipEvent_t fork_ev[RING] = {}, join_ev[RING] = {};
@@ -158,6 +159,10 @@ int mirt_init(int device) {
   if (const char *s = getenv("MIRT_BLOCKS_PER_CU")) {
     int v = atoi(s);
     if (v >= 1 && v <= 16) G.blocks_per_cu = v;
+  }
+  if (const char *s = getenv("MIRT_MIN_LANES")) {
+    int v = atoi(s);
+    if (v >= 0 && v <= 64) G.min_lanes = (uint32_t) v;
   }
   G.device = device;
   G.ready = true;
@@ -383,7 +388,7 @@ int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
   HIPCHK(s->redo_q[1].ensure(kn * 4));
   HIPCHK(s->mf_queue.ensure(n * 4));
   HIPCHK(s->ctrl.ensure(CTRL_WORDS * 4));
-  HIPCHK(s->ray_stats.ensure(8 * 8));
+  HIPCHK(s->ray_stats.ensure(16 * 8));
   return MIRT_OK;
 }
 
@@ -396,6 +401,7 @@ TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal) {
   t.tris = traversal == 0 ? s->trisf.as<float4>() : s->tris.as<float4>();
   t.tris2 = s->tris.as<float4>();
   t.require_unit = traversal == 0 ? 1 : 0;
+  t.min_lanes = G.min_lanes;
   t.big = s->big.as<uint2>();
   t.ray_o = s->ray_o.as<float4>();
   t.ray_d = s->ray_d.as<float4>();
@@ -424,6 +430,7 @@ TraceArgs shadow_args(mirt_scene *s, uint32_t traversal) {
   t.tris = traversal == 0 ? s->trisf.as<float4>() : s->tris.as<float4>();
   t.tris2 = s->tris.as<float4>();
   t.require_unit = traversal == 0 ? 1 : 0;
+  t.min_lanes = G.min_lanes;
   t.big = s->big.as<uint2>();
   t.ray_o = s->sh_o.as<float4>();
   t.ray_d = s->sh_d.as<float4>();
@@ -537,7 +544,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   HIPCHK(hipEventCreate(&evB));
 
   HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
-  HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, 64, G.stream));
+  HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, 128, G.stream));
   HIPCHK(hipMemsetAsync(s->ctrl.p, 0, CTRL_WORDS * 4, G.stream));
   HIPCHK(hipEventRecord(evA, G.stream));
   uint32_t iters = 0;
@@ -607,8 +614,8 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     n_kind[t.kind]++;
   }
   if (stats) {
-    unsigned long long rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIPCHK(hipMemcpy(rs, s->ray_stats.p, 64, hipMemcpyDeviceToHost));
+    unsigned long long rs[16] = {0};
+    HIPCHK(hipMemcpy(rs, s->ray_stats.p, 128, hipMemcpyDeviceToHost));
     memset(stats, 0, sizeof *stats);
     stats->closest_rays = n_camera + n_bounced;
     stats->shadow_rays = n_shadow_rays;
@@ -626,6 +633,10 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     stats->closest_tri_tests = rs[5];
     stats->shadow_node_visits = rs[6];
     stats->shadow_tri_tests = rs[7];
+    stats->closest_node_steps = rs[8];
+    stats->closest_tri_steps = rs[9];
+    stats->shadow_node_steps = rs[10];
+    stats->shadow_tri_steps = rs[11];
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   }
   return MIRT_OK;

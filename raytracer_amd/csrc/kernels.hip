@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
   uint32_t w_next = 0, w_end = 0, part = blockIdx.x & (WORK_PARTS - 1), parts_tried = 0;
   bool wave_done = (total == 0);
   int sp = 0;
-  uint32_t n_nodes = 0, n_tris = 0;
+  uint32_t n_nodes = 0, n_tris = 0, n_node_steps = 0, n_tri_steps = 0;   // COUNT: work items and wave-level steps
 
   auto push = [&](uint32_t ref, float tmn) {
     if (sp < LDS_STACK) lds_stack[sp * TRACE_BLOCK + tid] = make_uint2(ref, f2u(tmn));
@@ -704,7 +704,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
     // ---------------------------------------------------------------- inner nodes
     while (active && cur != CHILD_EMPTY && !(cur & CHILD_LEAF)) {
       const float4 *np = a.nodes4 + 8 * (size_t) cur;
-      if (COUNT) n_nodes++;
+      if (COUNT) {
+        n_nodes++;
+        if (lane_rank(__ballot(1)) == 0) n_node_steps++;
+      }
       const float4 LX = np[0], LY = np[1], LZ = np[2], HX = np[3], HY = np[4], HZ = np[5];
       const float4 CHf = np[6];
       const float lox[4] = {LX.x, LX.y, LX.z, LX.w}, loy[4] = {LY.x, LY.y, LY.z, LY.w}, loz[4] = {LZ.x, LZ.y, LZ.z, LZ.w};
@@ -768,7 +771,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
       bool found = false, irregular = false;
       for (uint32_t i = start; i < start + cnt; i++) {
         float t, by, bz;
-        if (COUNT) n_tris++;
+        if (COUNT) {
+          n_tris++;
+          if (lane_rank(__ballot(1)) == 0) n_tri_steps++;
+        }
         uint32_t flat;
         bool acc, near = false;
         if (MODE == 0) acc = tri_test_near(a.tris, i, r, r.best_t, NEAR, t, by, bz, flat, near);
@@ -809,10 +815,256 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
     for (int o = 32; o > 0; o >>= 1) {
       n_nodes += __shfl_xor(n_nodes, o);
       n_tris += __shfl_xor(n_tris, o);
+      n_node_steps += __shfl_xor(n_node_steps, o);
+      n_tri_steps += __shfl_xor(n_tri_steps, o);
     }
     if ((tid & 63) == 0) {
       atomicAdd(a.count_stat + 0, (unsigned long long) n_nodes);
       atomicAdd(a.count_stat + 1, (unsigned long long) n_tris);
+      atomicAdd(a.count_stat + 4, (unsigned long long) n_node_steps);
+      atomicAdd(a.count_stat + 5, (unsigned long long) n_tri_steps);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------- k_trace_fast (traversal 0)
+// The ordered traversal of the library's own SAH tree.  Its result must equal the reference's, not its arithmetic: the
+// nearest hit of a ray does not depend on the tree, the boxes or the visiting order unless two candidates (or a candidate
+// and one of the ray's t limits) lie within NEAR of each other, and those rays are handed to the reference walk (k_redo).
+// So the box test only has to be conservative, which buys:
+//   * slabs as one fma per plane, t = plane * inv - o * inv, with the near / far plane picked by the direction's sign
+//     through the load address (no min/max per axis); the rounding of o * inv is covered by widening each axis by
+//     AXIS_EPS * |o * inv| and the comparison by SLACK;
+//   * one loop in which every lane advances by one node OR one triangle per trip ("if-if"): the while-while form left
+//     75 % of the lanes idle in the node loop on this tree (tools/count_frame.py).  A part runs only when at least
+//     MIN_LANES lanes want it or it is the majority, so stragglers wait for company instead of issuing for themselves.
+// The triangle test itself is the exact one (tri_test_near).
+constexpr int FAST_MIN_LANES = 16;
+
+template<bool ANY, bool COUNT>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
+  constexpr float NEAR = 1.0e-5f;
+  constexpr float SLACK = 1.0f + 2.5e-5f;
+  constexpr float AXIS_EPS = 4.76837158e-7f;              // 2^-21
+  constexpr float INV_LIMIT = 1.0e15f;                    // steeper than this against an axis: reference walk
+
+  extern __shared__ uint2 lds_stack[];                    // [LDS_STACK][TRACE_BLOCK]
+  const uint32_t tid = threadIdx.x;
+  const uint32_t gtid = blockIdx.x * TRACE_BLOCK + tid;
+  const uint32_t nthreads = gridDim.x * TRACE_BLOCK;
+  const uint32_t nA = a.qcount[a.qc_front];
+  const uint32_t total = nA + (a.qc_back >= 0 ? a.qcount[a.qc_back] : 0);
+
+  LaneRay r;
+  r.id = 0; r.best_idx = -1; r.best_t = 0; r.min_t = 0; r.b1 = r.b2 = 0;
+  r.o = r.d = r.inv = mk(0, 0, 0);
+  V3 c_near = mk(0, 0, 0), c_far = mk(0, 0, 0);           // -(o * inv) widened down / up
+  uint32_t off_x = 0, off_y = 0, off_z = 0;               // 0: the near plane is the box minimum, 48: the maximum
+  bool active = false;
+  uint32_t cur = CHILD_EMPTY, tri_i = 0, tri_n = 0;
+  const uint32_t psz = ((total + WORK_PARTS - 1) / WORK_PARTS + 63u) & ~63u;
+  uint32_t chunk = (total / (gridDim.x * (TRACE_BLOCK / 64) * 4u)) & ~31u;
+  chunk = chunk < 32u ? 32u : (chunk > 256u ? 256u : chunk);
+  uint32_t w_next = 0, w_end = 0, part = blockIdx.x & (WORK_PARTS - 1), parts_tried = 0;
+  bool wave_done = (total == 0);
+  int sp = 0;
+  uint32_t n_nodes = 0, n_tris = 0, n_node_steps = 0, n_tri_steps = 0;
+
+  auto enter = [&](uint32_t ref) {
+    cur = ref;
+    if (ref != CHILD_EMPTY && (ref & CHILD_LEAF)) {
+      tri_i = ref & ((1u << LEAF_COUNT_SHIFT) - 1);
+      tri_n = (ref >> LEAF_COUNT_SHIFT) & 15u;              // the SAH tree has no oversized leaves
+    }
+  };
+  auto push = [&](uint32_t ref, float tmn) {
+    if (sp < LDS_STACK) lds_stack[sp * TRACE_BLOCK + tid] = make_uint2(ref, f2u(tmn));
+    else if (sp < LDS_STACK + (int) a.ovf_depth) a.ovf[(size_t) (sp - LDS_STACK) * nthreads + gtid] = make_uint2(ref, f2u(tmn));
+    else { atomicOr(a.error_flag, 2u); return; }
+    sp++;
+  };
+  auto pop = [&]() {
+    uint32_t next = CHILD_EMPTY;
+    while (sp > 0) {
+      sp--;
+      uint2 e = (sp < LDS_STACK) ? lds_stack[sp * TRACE_BLOCK + tid] : a.ovf[(size_t) (sp - LDS_STACK) * nthreads + gtid];
+      if (ANY || u2f(e.y) <= r.best_t * SLACK) { next = e.x; break; }
+    }
+    enter(next);
+  };
+
+  while (true) {
+    // ---------------------------------------------------------------- dynamic fetch (see k_trace4)
+    const uint64_t need = __ballot(!active);
+    if (need != 0 && !wave_done) {
+      if (w_next >= w_end) {
+        while (parts_tried < (uint32_t) WORK_PARTS) {
+          uint32_t got = 0;
+          if ((tid & 63) == 0) got = atomicAdd(a.work_head + CTR_STRIDE * part, chunk);
+          got = __builtin_amdgcn_readfirstlane(got);
+          const uint32_t lo = part * psz + got;
+          if (got < psz && lo < total) {
+            const uint32_t hi_part = (part + 1) * psz < total ? (part + 1) * psz : total;
+            w_next = lo;
+            w_end = lo + chunk < hi_part ? lo + chunk : hi_part;
+            break;
+          }
+          part = (part + 1) & (WORK_PARTS - 1);
+          parts_tried++;
+        }
+        if (w_next >= w_end) wave_done = true;
+      }
+      if (!wave_done) {
+        if (!active) {
+          const uint32_t w = w_next + lane_rank(need);
+          if (w < w_end) {
+            const uint32_t id = (w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)];
+            load_ray(a, id, r);
+            // Rays the shortcut arithmetic is not meant for take the reference walk: non-finite origin / direction /
+            // reciprocal (the reference's result then depends on its visiting order), a direction almost parallel to an
+            // axis plane (o * inv would lose all precision), and ctor directions that are not unit length (the reference
+            // prunes boxes along the un-normalised direction but measures hits along the normalised one, ray.cuh:19-21).
+            const float4 rd = a.ray_d[id];
+            const float l2 = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
+            const bool regular = finite3(r.o) && finite3(r.d) && (r.best_t == r.best_t) && (r.min_t == r.min_t) &&
+                                 fabsf(r.inv.x) < INV_LIMIT && fabsf(r.inv.y) < INV_LIMIT && fabsf(r.inv.z) < INV_LIMIT &&
+                                 (fabsf(l2 - 1.0f) < 1e-4f);
+            if (regular) {
+              const V3 oi = mk(r.o.x * r.inv.x, r.o.y * r.inv.y, r.o.z * r.inv.z);
+              c_near = mk(-oi.x - AXIS_EPS * fabsf(oi.x), -oi.y - AXIS_EPS * fabsf(oi.y), -oi.z - AXIS_EPS * fabsf(oi.z));
+              c_far = mk(-oi.x + AXIS_EPS * fabsf(oi.x), -oi.y + AXIS_EPS * fabsf(oi.y), -oi.z + AXIS_EPS * fabsf(oi.z));
+              off_x = r.inv.x < 0 ? 48u : 0u;
+              off_y = r.inv.y < 0 ? 48u : 0u;
+              off_z = r.inv.z < 0 ? 48u : 0u;
+              active = true;
+              sp = 0;
+              enter(0);
+            } else {
+              const uint32_t pos = wave_reserve(a.redo_count, 1);
+              a.redo_queue[pos] = id;
+            }
+          }
+        }
+        const uint32_t taken = (uint32_t) __popcll(need);
+        w_next = (w_end - w_next) < taken ? w_end : w_next + taken;
+      }
+    }
+    if (!__any(active)) {
+      if (wave_done) break;
+      continue;
+    }
+
+    // ---------------------------------------------------------------- one step per lane: a node ...
+    const bool at_node = active && !(cur & CHILD_LEAF);
+    const int cn = __popcll(__ballot(at_node)), cl = __popcll(__ballot(active && !at_node));
+    const bool run_nodes = cn > 0 && (cn >= (int) a.min_lanes || cn >= cl);
+    if (run_nodes && at_node) {
+      const char *nb = (const char *) a.nodes4 + (size_t) cur * 128u;
+      if (COUNT) {
+        n_nodes++;
+        if (lane_rank(__ballot(1)) == 0) n_node_steps++;
+      }
+      const float4 NX = *(const float4 *) (nb + off_x), FX = *(const float4 *) (nb + (48u - off_x));
+      const float4 NY = *(const float4 *) (nb + 16u + off_y), FY = *(const float4 *) (nb + (64u - off_y));
+      const float4 NZ = *(const float4 *) (nb + 32u + off_z), FZ = *(const float4 *) (nb + (80u - off_z));
+      const float4 CHf = *(const float4 *) (nb + 96u);
+      const float nx[4] = {NX.x, NX.y, NX.z, NX.w}, ny[4] = {NY.x, NY.y, NY.z, NY.w}, nz[4] = {NZ.x, NZ.y, NZ.z, NZ.w};
+      const float fx[4] = {FX.x, FX.y, FX.z, FX.w}, fy[4] = {FY.x, FY.y, FY.z, FY.w}, fz[4] = {FZ.x, FZ.y, FZ.z, FZ.w};
+      uint32_t ch[4] = {f2u(CHf.x), f2u(CHf.y), f2u(CHf.z), f2u(CHf.w)};
+      float key[4];
+      const float far_limit = r.best_t;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const float tnx = fmaf(nx[c], r.inv.x, c_near.x), tny = fmaf(ny[c], r.inv.y, c_near.y), tnz = fmaf(nz[c], r.inv.z, c_near.z);
+        const float tfx = fmaf(fx[c], r.inv.x, c_far.x), tfy = fmaf(fy[c], r.inv.y, c_far.y), tfz = fmaf(fz[c], r.inv.z, c_far.z);
+        const float tmn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tmx = fminf(fminf(tfx, tfy), fminf(tfz, far_limit)) * SLACK;
+        const bool hit = (ch[c] != CHILD_EMPTY) && (tmn <= tmx) && (tmx > r.min_t);
+        key[c] = hit ? tmn : MIRT_INF;
+        if (!hit) ch[c] = CHILD_EMPTY;
+      }
+      if (!ANY) {
+#define MIRT_CE(i, j)                                                         \
+  {                                                                           \
+    const bool sw = key[j] < key[i];                                          \
+    const float ki = sw ? key[j] : key[i], kj = sw ? key[i] : key[j];         \
+    const uint32_t ci = sw ? ch[j] : ch[i], cj = sw ? ch[i] : ch[j];          \
+    key[i] = ki; key[j] = kj; ch[i] = ci; ch[j] = cj;                         \
+  }
+        MIRT_CE(0, 1) MIRT_CE(2, 3) MIRT_CE(0, 2) MIRT_CE(1, 3) MIRT_CE(1, 2)
+#undef MIRT_CE
+      }
+      uint32_t first = CHILD_EMPTY;
+#pragma unroll
+      for (int c = 3; c >= 0; c--) {
+        if (ch[c] != CHILD_EMPTY) {
+          bool earlier = false;
+#pragma unroll
+          for (int e = 0; e < c; e++) earlier = earlier || (ch[e] != CHILD_EMPTY);
+          if (earlier) push(ch[c], key[c]);
+          else first = ch[c];
+        }
+      }
+      if (first != CHILD_EMPTY) enter(first);
+      else pop();
+    }
+
+    // ---------------------------------------------------------------- ... or a triangle (lanes that just reached a leaf join in)
+    const bool at_leaf = active && cur != CHILD_EMPTY && (cur & CHILD_LEAF);
+    const int cl2 = __popcll(__ballot(at_leaf));
+    if (cl2 > 0 && (cl2 >= (int) a.min_lanes || !run_nodes) && at_leaf) {
+      float t, by, bz;
+      uint32_t flat;
+      bool near = false;
+      if (COUNT) {
+        n_tris++;
+        if (lane_rank(__ballot(1)) == 0) n_tri_steps++;
+      }
+      const bool acc = tri_test_near(a.tris, tri_i, r, r.best_t, NEAR, t, by, bz, flat, near);
+      tri_i++;
+      tri_n--;
+      if (near || (acc && !(fabsf(t) < MIRT_INF))) {
+        // two candidates (or a candidate and a limit) too close to call, or an accepted NaN / inf hit
+        const uint32_t pos = wave_reserve(a.redo_count, 1);
+        a.redo_queue[pos] = r.id;
+        active = false;
+      } else {
+        if (acc) {
+          r.best_t = t; r.b1 = by; r.b2 = bz; r.best_idx = (int32_t) flat;
+          if (ANY) {
+            a.occ[r.id] = 1u;
+            if (a.any_t) a.any_t[r.id] = r.best_t;
+            active = false;
+          }
+        }
+        if (active && tri_n == 0) pop();
+      }
+    }
+
+    // ---------------------------------------------------------------- ray finished
+    if (active && cur == CHILD_EMPTY) {
+      if (ANY) {
+        a.occ[r.id] = 0u;
+        if (a.any_t) a.any_t[r.id] = r.best_t;
+      } else {
+        a.hit[r.id] = make_float4(r.best_t, r.b1, r.b2, u2f((uint32_t) r.best_idx));
+      }
+      active = false;
+    }
+  }
+  if (COUNT) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      n_nodes += __shfl_xor(n_nodes, o);
+      n_tris += __shfl_xor(n_tris, o);
+      n_node_steps += __shfl_xor(n_node_steps, o);
+      n_tri_steps += __shfl_xor(n_tri_steps, o);
+    }
+    if ((tid & 63) == 0) {
+      atomicAdd(a.count_stat + 0, (unsigned long long) n_nodes);
+      atomicAdd(a.count_stat + 1, (unsigned long long) n_tris);
+      atomicAdd(a.count_stat + 4, (unsigned long long) n_node_steps);
+      atomicAdd(a.count_stat + 5, (unsigned long long) n_tri_steps);
     }
   }
 }
@@ -928,7 +1180,7 @@ size_t trace4_lds_bytes() { return (size_t) LDS_STACK * TRACE_BLOCK * sizeof(uin
 
 int trace4_blocks_per_cu() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace4<false, 0, false>, TRACE_BLOCK, trace4_lds_bytes()) != hipSuccess || nb < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_fast<false, false>, TRACE_BLOCK, trace4_lds_bytes()) != hipSuccess || nb < 1)
     nb = 2;
   return nb;
 }
@@ -944,15 +1196,14 @@ hipError_t launch_trace(const TraceArgs &a, bool any, uint32_t traversal, uint32
   } else {
     const size_t lds = trace4_lds_bytes();
     if (any && traversal == 0) {
-      // any-hit never sorts children (the boolean does not depend on the order); MODE only selects the slack rule
-      if (a.count) k_trace4<true, 0, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-      else k_trace4<true, 0, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      if (a.count) k_trace_fast<true, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      else k_trace_fast<true, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
     } else if (any) {
       if (a.count) k_trace4<true, 1, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
       else k_trace4<true, 1, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
     } else if (traversal == 0) {
-      if (a.count) k_trace4<false, 0, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-      else k_trace4<false, 0, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      if (a.count) k_trace_fast<false, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      else k_trace_fast<false, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
     } else {
       if (a.count) k_trace4<false, 1, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
       else k_trace4<false, 1, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);

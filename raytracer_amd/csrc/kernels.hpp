@@ -67,6 +67,7 @@ struct TraceArgs {
   unsigned long long *redo_stat;          // counts rays re-traced by the reference walk (may be null)
   unsigned long long *count_stat;         // [0] node visits, [1] triangle tests (counting launches only)
   uint32_t count;
+  uint32_t min_lanes;                     // k_trace_fast: lanes a loop part waits for before it runs (unless it is the majority)
   uint32_t require_unit;                  // traversal 0: rays whose ctor direction is not unit length go to k_trace2
 };
 
