@@ -51,13 +51,25 @@ def parse():
     return ap.parse_args()
 
 
+def traffic_per_launch():
+    """HBM bytes per launch of the dominant kernel, from the committed PMC passes of this same command (rocprofv3 cannot
+    wrap itself: tools/make_profiles.sh collects FETCH_SIZE / WRITE_SIZE in separate runs, profiles/traffic.json holds the
+    corrected figure).  None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            return json.load(fh)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(scene_data, args):
-    """Reference CPU path on a bounded sample of the same workload: quarter-resolution frame, 8 spp, same depth."""
+    """Reference CPU path on a bounded sample of the same workload: half-resolution frame (a quarter of the pixels), same
+    spp and depth: ~10-20 s of work for 16 threads."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cpulibs import CpuTracer, ref_available
 
     threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-    w, h, spp = args.width // 4, args.height // 4, 8
+    w, h, spp = args.width // 2, args.height // 2, args.spp
     cam = scene_data.camera
     kw = dict(spp=spp, spl=1, batch=spp + 1, tol=0.0, depth=args.depth, nthreads=threads)
     orc = CpuTracer("oracle").load(scene_data)
@@ -177,8 +189,8 @@ def main():
                        "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
                        "scene_build_s": build_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_trace4<closest>", "avg_launch_ms": avg_launch_ms, "launches": launches,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_per_launch(),
+                         "kernel": "k_trace_fast<closest>" if args.traversal == 0 else "k_trace4<closest>", "avg_launch_ms": avg_launch_ms, "launches": launches,
                          "bytes_per_ray": b_ray, "node_visits_per_ray": n_node, "tri_tests_per_ray": n_tri,
                          "kernel_rays_per_s": k_rays / (k_ms * 1e-3) if k_ms > 0 else 0.0,
                          "shadow_kernel_ms": sum(s["trace_shadow_ms"] for s in stats),

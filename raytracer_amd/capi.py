@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmirt.so")
+LIB_PATH = os.environ.get("MIRT_LIB") or os.path.join(_HERE, "libmirt.so")   # MIRT_LIB: tuning builds (tools/build_variant.sh)
 
 SYMBOLS = [
     "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_version", "mirt_scene_create", "mirt_scene_destroy",

@@ -1,3 +1,4 @@
+#include <cstdlib>
 // See host_bvh.hpp.  Compiled without FMA contraction: every float here must round as the reference's g++ build does.
 #include "host_bvh.hpp"
 
@@ -256,7 +257,7 @@ void collapse_to_wide(HostBVH &bvh) {
 
 // ------------------------------------------------------------------------------------------------ fast tree
 // The tree the ordered traversal (mirt_options.traversal = 0) walks.  It is NOT the reference's: binned-SAH splits over
-// tight per-triangle boxes, leaves of at most 4 triangles, its own triangle order (each packed triangle carries its flat
+// tight per-triangle boxes, leaves of at most 3 triangles, its own triangle order (each packed triangle carries its flat
 // index of the reference order, which is what hit indices and the tie rule are expressed in).  Any tree over the same
 // triangles yields the reference's closest hit (minimum t, ties to the larger flat index) as long as its boxes contain
 // their triangles, which exact min/max of the vertices guarantees.
@@ -400,7 +401,11 @@ void build_fast_tree(const float *tri_pos_flat, uint32_t n, HostBVH &bvh) {
   bvh.fast_to_flat.reserve(n);
   SahBuilder sb(n2, bvh.fast_to_flat);
   sb.pos = tri_pos_flat;
-  sb.max_leaf = 4;
+  sb.max_leaf = 3;                                         // measured best of 1..8 on the bench workload (tools/sweep.sh MIRT_FAST_LEAF)
+  if (const char *e = std::getenv("MIRT_FAST_LEAF")) {     // tuning knob (1..15: the inline leaf count field)
+    int v = std::atoi(e);
+    if (v >= 1 && v <= (int) LEAF_MAX) sb.max_leaf = (uint32_t) v;
+  }
   sb.prepare(n);
   sb.build(0, n);
   bvh.nodes4f.clear();

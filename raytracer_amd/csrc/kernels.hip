@@ -841,8 +841,11 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
 // The triangle test itself is the exact one (tri_test_near).
 constexpr int FAST_MIN_LANES = 16;
 
+#ifndef MIRT_FAST_ATTR
+#define MIRT_FAST_ATTR
+#endif
 template<bool ANY, bool COUNT>
-__global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
+__global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(TraceArgs a) {
   constexpr float NEAR = 1.0e-5f;
   constexpr float SLACK = 1.0f + 2.5e-5f;
   constexpr float AXIS_EPS = 4.76837158e-7f;              // 2^-21

@@ -9,7 +9,10 @@
 namespace mirt {
 
 constexpr int TRACE_BLOCK = 256;
-constexpr int LDS_STACK = 12;        // traversal-stack entries per lane kept in LDS (8 B each): 24 KiB per workgroup
+#ifndef MIRT_LDS_STACK
+#define MIRT_LDS_STACK 12
+#endif
+constexpr int LDS_STACK = MIRT_LDS_STACK;        // traversal-stack entries per lane kept in LDS (8 B each): 24 KiB per workgroup
 constexpr int BVH2_STACK = 64;       // k_trace2 (the reference uses 32 unchecked, util/misc.cuh:19)
 
 // per-slot flag bits (RenderArgs::st[].z low byte)
