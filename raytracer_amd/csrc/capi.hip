@@ -63,6 +63,10 @@ struct Global {
   int n_cu = 0;
   int blocks_per_cu = 2;
   uint32_t min_lanes = 16;
+  uint32_t fast_width = 8;
+  uint32_t refill_min = 8;
+  bool serial = false;
+  uint32_t static_16th = 12;
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;            // runs the closest-hit redo pass next to the shadow launch of the main stream
   hipEvent_t fork_ev[RING] = {}, join_ev[RING] = {};
@@ -104,14 +108,15 @@ struct mirt_scene {
   HostBVH bvh;
   uint32_t n_tris = 0, n_mats = 0, n_lights = 0;
   bool has_microfacet = false;
-  DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big, nodes4f, trisf;
+  bool fast_ok = true;                   // false: the SAH tree could not be built (non-finite vertices): traversal 0 runs as 1
+  DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big, nodes4f, trisf, nodes8q;
   uint32_t ovf_depth = 0;
   uint32_t trace_threads = 0;
   // work buffers (sized per render)
   DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2], mf_queue;
   DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t;
   size_t device_bytes() const {
-    const DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &nodes4f, &trisf, &st, &mask, &total, &accum, &dmask,
+    const DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &nodes4f, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                            &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0],
                            &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue};
     size_t s = 0;
@@ -119,7 +124,7 @@ struct mirt_scene {
     return s;
   }
   void release_all() {
-    DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &nodes4f, &trisf, &st, &mask, &total, &accum, &dmask,
+    DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &nodes4f, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                      &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0], &redo_q[1],
                      &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue};
     for (auto *b: all) b->release();
@@ -159,6 +164,16 @@ int mirt_init(int device) {
   if (const char *s = getenv("MIRT_BLOCKS_PER_CU")) {
     int v = atoi(s);
     if (v >= 1 && v <= 16) G.blocks_per_cu = v;
+  }
+  if (const char *s = getenv("MIRT_FAST_WIDTH")) G.fast_width = atoi(s) == 4 ? 4u : 8u;
+  if (const char *s = getenv("MIRT_SERIAL")) G.serial = atoi(s) != 0;
+  if (const char *s = getenv("MIRT_STATIC_16TH")) {
+    int v = atoi(s);
+    if (v >= 0 && v <= 16) G.static_16th = (uint32_t) v;
+  }
+  if (const char *s = getenv("MIRT_REFILL_MIN")) {
+    int v = atoi(s);
+    if (v >= 1 && v <= 64) G.refill_min = (uint32_t) v;
   }
   if (const char *s = getenv("MIRT_MIN_LANES")) {
     int v = atoi(s);
@@ -237,9 +252,17 @@ int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t
     std::vector<float> flat_pos((size_t) n_tris * 9);
     for (uint32_t f = 0; f < n_tris; f++)
       memcpy(&flat_pos[(size_t) f * 9], tri_pos + 9 * (size_t) s->bvh.flat_to_orig[f], 9 * sizeof(float));
-    build_fast_tree(flat_pos.data(), n_tris, s->bvh);
-    for (uint32_t j = 0; j < n_tris; j++)
-      memcpy(&trif[(size_t) j * 12], &tri[(size_t) s->bvh.fast_to_flat[j] * 12], 12 * sizeof(float));
+    try {
+      build_fast_tree(flat_pos.data(), n_tris, s->bvh);
+    } catch (const std::exception &) {
+      s->fast_ok = false;
+      s->bvh.nodes4f.clear();
+      s->bvh.nodes8q.clear();
+      s->bvh.depth4f = s->bvh.depth8 = 0;
+    }
+    if (s->fast_ok)
+      for (uint32_t j = 0; j < n_tris; j++)
+        memcpy(&trif[(size_t) j * 12], &tri[(size_t) s->bvh.fast_to_flat[j] * 12], 12 * sizeof(float));
   }
   // materials: mirt_bsdf records (9 dwords) padded to three float4
   std::vector<float> mats_padded((size_t) n_mats * 12, 0.f);
@@ -255,14 +278,17 @@ int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t
   bool ok = up(s->tris, tri.data(), tri.size() * 4) && up(s->tri_nrm, nrm.data(), nrm.size() * 4) &&
             up(s->nodes4, s->bvh.nodes4.data(), s->bvh.nodes4.size() * sizeof(Node4)) &&
             up(s->nodes2, s->bvh.nodes2.data(), s->bvh.nodes2.size() * sizeof(Node2)) &&
-            up(s->nodes4f, s->bvh.nodes4f.data(), s->bvh.nodes4f.size() * sizeof(Node4)) &&
+            up(s->nodes4f, s->bvh.nodes4f.empty() ? (const void *) tri.data() : (const void *) s->bvh.nodes4f.data(),
+               s->bvh.nodes4f.empty() ? 16 : s->bvh.nodes4f.size() * sizeof(Node4)) &&
             up(s->trisf, trif.data(), trif.size() * 4) &&
+            up(s->nodes8q, s->bvh.nodes8q.empty() ? (const void *) tri.data() : (const void *) s->bvh.nodes8q.data(),
+               s->bvh.nodes8q.empty() ? 16 : s->bvh.nodes8q.size() * 4) &&
             up(s->mats, mats_padded.data(), mats_padded.size() * 4) &&
             up(s->big, s->bvh.big.empty() ? (const void *) mats : (const void *) s->bvh.big.data(), s->bvh.big.empty() ? 8 : s->bvh.big.size() * 4) &&
             up(s->lights, lights ? (const void *) lights : (const void *) mats, n_lights ? (size_t) n_lights * sizeof(mirt_light) : 4);
   if (ok) {
     s->trace_threads = (uint32_t) (G.n_cu * G.blocks_per_cu * TRACE_BLOCK);
-    int need = 3 * ((int) std::max(s->bvh.depth4, s->bvh.depth4f) + 2) - LDS_STACK + 1;
+    int need = std::max(3 * ((int) std::max(s->bvh.depth4, s->bvh.depth4f) + 2), 7 * ((int) s->bvh.depth8 + 2)) - LDS_STACK + 1;
     s->ovf_depth = (uint32_t) (need > 1 ? need : 1);
     ok = s->ovf.ensure((size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
   }
@@ -402,6 +428,10 @@ TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal) {
   t.tris2 = s->tris.as<float4>();
   t.require_unit = traversal == 0 ? 1 : 0;
   t.min_lanes = G.min_lanes;
+  t.nodes8 = s->nodes8q.p;
+  t.width = G.fast_width;
+  t.refill_min = G.refill_min;
+  t.static_16th = G.static_16th;
   t.big = s->big.as<uint2>();
   t.ray_o = s->ray_o.as<float4>();
   t.ray_d = s->ray_d.as<float4>();
@@ -431,6 +461,10 @@ TraceArgs shadow_args(mirt_scene *s, uint32_t traversal) {
   t.tris2 = s->tris.as<float4>();
   t.require_unit = traversal == 0 ? 1 : 0;
   t.min_lanes = G.min_lanes;
+  t.nodes8 = s->nodes8q.p;
+  t.width = G.fast_width;
+  t.refill_min = G.refill_min;
+  t.static_16th = G.static_16th;
   t.big = s->big.as<uint2>();
   t.ray_o = s->sh_o.as<float4>();
   t.ray_d = s->sh_d.as<float4>();
@@ -450,35 +484,26 @@ TraceArgs shadow_args(mirt_scene *s, uint32_t traversal) {
   return t;
 }
 
-// One trace launch plus the reference walk over the rays it set aside.  With `fork_slot >= 0` the redo pass runs on the
-// side stream (it is a handful of rays walking serially: latency, not throughput) and the caller joins
-// G.join_ev[fork_slot] into the main stream before anything reads the results.
-int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, std::vector<Timed> *timed, bool count = false,
-              int fork_slot = -1) {
+// One trace launch plus the reference walk over the rays it set aside, on `stream`.
+int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, std::vector<Timed> *timed, bool count,
+              hipStream_t stream) {
   const uint32_t grid = s->trace_threads / TRACE_BLOCK;
   Timed tm{any ? 2 : 1, nullptr, nullptr};
   if (timed) {
     tm.a = G.pool_next();
     tm.b = G.pool_next();
     if (!tm.a || !tm.b) return fail(MIRT_E_DEVICE, "could not create timing events");
-    HIPCHK(hipEventRecord(tm.a, G.stream));
+    HIPCHK(hipEventRecord(tm.a, stream));
   }
   t.count = count ? 1 : 0;
-  HIPCHK(launch_trace(t, any, traversal, grid, G.stream));
+  HIPCHK(launch_trace(t, any, traversal, grid, stream));
   if (timed) {
-    HIPCHK(hipEventRecord(tm.b, G.stream));
+    HIPCHK(hipEventRecord(tm.b, stream));
     timed->push_back(tm);
   }
   if (traversal != 2) {
     t.redo = 1;
-    if (fork_slot >= 0) {
-      HIPCHK(hipEventRecord(G.fork_ev[fork_slot], G.stream));
-      HIPCHK(hipStreamWaitEvent(G.side, G.fork_ev[fork_slot], 0));
-      HIPCHK(launch_trace(t, any, 2, 256, G.side));
-      HIPCHK(hipEventRecord(G.join_ev[fork_slot], G.side));
-    } else {
-      HIPCHK(launch_trace(t, any, 2, 256, G.stream));
-    }
+    HIPCHK(launch_trace(t, any, 2, 256, stream));
   }
   return MIRT_OK;
 }
@@ -497,6 +522,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   memset(&o, 0, sizeof o);
   if (opts_in) o = *opts_in;
   if (o.rng_mode > 1 || o.traversal > 2) return fail(MIRT_E_ARG, "bad rng_mode / traversal");
+  if (o.traversal == 0 && !s->fast_ok) o.traversal = 1;
   if (o.tile_world > 1 && o.tile_rank >= o.tile_world) return fail(MIRT_E_ARG, "tile_rank >= tile_world");
   const bool sliced = o.sample_count != 0 || o.sample_begin != 0;
   if (sliced && o.rng_mode != 1) return fail(MIRT_E_ARG, "spp slices need rng_mode 1 (the xorshift stream is sequential per pixel)");
@@ -576,11 +602,20 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
       const int slot = (int) (it % RING);
       HIPCHK(hipMemcpyAsync(G.h_counts + slot * QC_WORDS, ctrl + CTRL_QCOUNT, QC_WORDS * 4, hipMemcpyDeviceToHost, G.stream));
       HIPCHK(hipEventRecord(G.ring_ev[slot], G.stream));
-      const bool fork = K != 0 && o.traversal != 2;
-      rc = run_trace(s, tc, false, o.traversal, profile ? &timed : nullptr, counting, fork ? slot : -1);
+      // The two traversals of an iteration are independent: the shadow rays go to the side stream, so the tail of one
+      // launch (a few long rays, the GPU mostly idle) is filled by the other.  MIRT_SERIAL=1 keeps one stream.
+      const bool fork = K != 0 && !G.serial;
+      if (fork) {
+        HIPCHK(hipEventRecord(G.fork_ev[slot], G.stream));
+        HIPCHK(hipStreamWaitEvent(G.side, G.fork_ev[slot], 0));
+        rc = run_trace(s, ts, true, o.traversal, profile ? &timed : nullptr, counting, G.side);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(G.join_ev[slot], G.side));
+      }
+      rc = run_trace(s, tc, false, o.traversal, profile ? &timed : nullptr, counting, G.stream);
       if (rc) return rc;
-      if (K) {
-        rc = run_trace(s, ts, true, o.traversal, profile ? &timed : nullptr, counting);
+      if (K && !fork) {
+        rc = run_trace(s, ts, true, o.traversal, profile ? &timed : nullptr, counting, G.stream);
         if (rc) return rc;
       }
       if (fork) HIPCHK(hipStreamWaitEvent(G.stream, G.join_ev[slot], 0));
@@ -688,6 +723,7 @@ int mirt_primary_hits(mirt_scene *s, const mirt_camera *camera, const mirt_optio
   memset(&o, 0, sizeof o);
   if (opts_in) o = *opts_in;
   if (o.rng_mode > 1 || o.traversal > 2) return fail(MIRT_E_ARG, "bad rng_mode / traversal");
+  if (o.traversal == 0 && !s->fast_ok) o.traversal = 1;
   o.tile_rank = 0;
   o.tile_world = 1;
   const Partition part = make_partition(w, h, o);
@@ -710,7 +746,7 @@ int mirt_primary_hits(mirt_scene *s, const mirt_camera *camera, const mirt_optio
   HIPCHK(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, G.stream));
   HIPCHK(launch_init(a, G.stream));
   HIPCHK(launch_probe_primary(a, G.stream));
-  rc = run_trace(s, closest_args(s, part.n_slots, o.traversal), false, o.traversal, nullptr);
+  rc = run_trace(s, closest_args(s, part.n_slots, o.traversal), false, o.traversal, nullptr, false, G.stream);
   if (rc) return rc;
   HIPCHK(launch_gather_primary(a, s->probe_idx.as<int32_t>(), s->probe_t.as<uint32_t>(), G.stream));
   HIPCHK(hipMemcpyAsync(idx_out, s->probe_idx.p, n * 4, hipMemcpyDeviceToHost, G.stream));
@@ -727,6 +763,7 @@ int mirt_trace(mirt_scene *s, const float *rays, uint32_t n, int any_hit, uint32
   if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
   if (!s || !idx_out || !tbits_out) return fail(MIRT_E_ARG, "null argument");
   if (traversal > 2) return fail(MIRT_E_ARG, "bad traversal");
+  if (traversal == 0 && !s->fast_ok) traversal = 1;
   if (n == 0) return MIRT_OK;
   if (!rays) return fail(MIRT_E_ARG, "rays is null");
   int rc = ensure_work(s, n, 1);
@@ -756,7 +793,7 @@ int mirt_trace(mirt_scene *s, const float *rays, uint32_t n, int any_hit, uint32
     t = closest_args(s, n, traversal);
   }
   HIPCHK(hipStreamSynchronize(G.stream));     // the host staging vectors and &n must outlive the copies
-  rc = run_trace(s, t, any_hit != 0, traversal, nullptr);
+  rc = run_trace(s, t, any_hit != 0, traversal, nullptr, false, G.stream);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(G.stream));
   if (any_hit) {

@@ -3,6 +3,7 @@
 #include "host_bvh.hpp"
 
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <stdexcept>
 
@@ -394,6 +395,95 @@ uint32_t depth_of_nodes(const std::vector<Node2> &n, uint32_t i, uint32_t d) {
 
 }  // namespace
 
+// Folds the binary SAH tree to 8-wide nodes (largest-area child expanded first) and quantises the child boxes.
+struct Collapser8 {
+  const std::vector<Node2> &n2;
+  std::vector<Node8Q> out;
+  uint32_t max_depth = 0;
+  explicit Collapser8(const std::vector<Node2> &nodes) : n2(nodes) {}
+
+  uint32_t build(uint32_t root_id, uint32_t depth) {
+    const uint32_t id = (uint32_t) out.size();
+    out.emplace_back();
+    if (depth > max_depth) max_depth = depth;
+    const Node2 &root = n2[root_id];
+    uint32_t kids[8];
+    int nk = 0;
+    if (root.w0 & 0x80000000u) {
+      kids[nk++] = root_id;                              // a scene that is one leaf
+    } else {
+      kids[nk++] = root.w0;
+      kids[nk++] = root.w1;
+      while (nk < 8) {
+        int best = -1;
+        float best_a = -1.f;
+        for (int k = 0; k < nk; k++) {
+          const Node2 &c = n2[kids[k]];
+          if (c.w0 & 0x80000000u) continue;
+          const float a = half_area(c);
+          if (!(a <= best_a)) { best_a = a; best = k; }
+        }
+        if (best < 0) break;
+        const Node2 c = n2[kids[best]];
+        kids[best] = c.w0;
+        kids[nk++] = c.w1;
+      }
+    }
+    Node8Q q;
+    memset(&q, 0, sizeof q);
+    for (int k = 0; k < 8; k++) q.child[k] = CHILD_EMPTY;
+    // grid: origin = the node's minimum corner, step = smallest power of two that spans the extent in 255 steps
+    int eb[3];
+    double step[3];
+    for (int a = 0; a < 3; a++) {
+      q.p[a] = root.minp[a];
+      if (!std::isfinite(root.minp[a]) || !std::isfinite(root.maxp[a]))
+        throw std::runtime_error("non-finite vertex: no quantised tree");
+      const double ext = (double) root.maxp[a] - (double) root.minp[a];
+      int e = -126;
+      if (ext > 0) {
+        int fe;
+        (void) std::frexp(ext / 255.0, &fe);             // ext / 255 = m * 2^fe, m in [0.5, 1)  =>  2^fe >= ext / 255
+        e = fe;
+      }
+      if (e < -126) e = -126;
+      if (e > 127) throw std::runtime_error("scene extent too large for the quantised tree");
+      eb[a] = e + 127;
+      step[a] = std::ldexp(1.0, e);
+    }
+    q.exps = (uint32_t) eb[0] | ((uint32_t) eb[1] << 8) | ((uint32_t) eb[2] << 16);
+    uint8_t *qlo[3] = {q.qlo_x, q.qlo_y, q.qlo_z}, *qhi[3] = {q.qhi_x, q.qhi_y, q.qhi_z};
+    for (int k = 0; k < nk; k++) {
+      const Node2 &c = n2[kids[k]];
+      for (int a = 0; a < 3; a++) {
+        double lo = std::floor(((double) c.minp[a] - (double) q.p[a]) / step[a]);
+        double hi = std::ceil(((double) c.maxp[a] - (double) q.p[a]) / step[a]);
+        if (lo < 0) lo = 0;
+        if (hi > 255) hi = 255;
+        // exact in double: p + q * 2^e.  The quantised box must contain the child's box.
+        if ((double) q.p[a] + lo * step[a] > (double) c.minp[a] || (double) q.p[a] + hi * step[a] < (double) c.maxp[a])
+          throw std::runtime_error("quantised child box does not contain the exact one");
+        qlo[a][k] = (uint8_t) lo;
+        qhi[a][k] = (uint8_t) hi;
+      }
+    }
+    out[id] = q;
+    for (int k = 0; k < nk; k++) {
+      const Node2 &c = n2[kids[k]];
+      uint32_t ref;
+      if (c.w0 & 0x80000000u) {
+        const uint32_t count = c.w0 & 0x7fffffffu;
+        if (count == 0 || count > LEAF_MAX) throw std::runtime_error("SAH leaf outside 1..15 primitives");
+        ref = CHILD_LEAF | (count << LEAF_COUNT_SHIFT) | c.w1;
+      } else {
+        ref = build(kids[k], depth + 1);
+      }
+      out[id].child[k] = ref;                            // (re-index: `out` may have been reallocated)
+    }
+    return id;
+  }
+};
+
 void build_fast_tree(const float *tri_pos_flat, uint32_t n, HostBVH &bvh) {
   std::vector<Node2> n2;
   n2.reserve((size_t) n);
@@ -413,6 +503,11 @@ void build_fast_tree(const float *tri_pos_flat, uint32_t n, HostBVH &bvh) {
   Collapser c(CollapseIO{n2, bvh.nodes4f, big_unused});
   c.build(0, 0);
   bvh.depth4f = c.max_depth;
+  Collapser8 c8(n2);
+  c8.build(0, 0);
+  bvh.depth8 = c8.max_depth;
+  bvh.nodes8q.resize(c8.out.size() * (sizeof(Node8Q) / 4));
+  memcpy(bvh.nodes8q.data(), c8.out.data(), c8.out.size() * sizeof(Node8Q));
 }
 
 }  // namespace mirt

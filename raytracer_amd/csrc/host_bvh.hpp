@@ -47,7 +47,22 @@ struct HostBVH {
   std::vector<Node4> nodes4f;
   std::vector<uint32_t> fast_to_flat;        // fast-order slot -> flat (reference-order) index
   uint32_t depth4f = 0;
+  // the same SAH tree folded to 8-wide nodes with 8-bit quantised child boxes (96 bytes, Node8Q), what the kernel walks
+  std::vector<uint32_t> nodes8q;             // 24 words per node
+  uint32_t depth8 = 0;
 };
+
+// 8-wide node of the ordered traversal, 96 bytes = 6 x dwordx4.  Child k's box is, per axis,
+//   [ p + qlo[k] * 2^(e - 127),  p + qhi[k] * 2^(e - 127) ]   (qlo rounded down, qhi rounded up: it contains the exact box)
+// The ordered traversal only needs conservative boxes, so 8 bits per plane are enough.
+struct Node8Q {
+  float p[3];                                // minimum corner of the node's own box
+  uint32_t exps;                             // biased float exponents of the x, y, z grid steps: ex | ey << 8 | ez << 16
+  uint32_t child[8];                         // CHILD_EMPTY | inner node index | leaf reference
+  uint8_t qlo_x[8], qlo_y[8], qlo_z[8];      // byte k = child k
+  uint8_t qhi_x[8], qhi_y[8], qhi_z[8];
+};
+static_assert(sizeof(Node8Q) == 96, "Node8Q layout");
 
 // tri_pos: n x 9 floats.  Throws std::runtime_error on limits.
 void build_reference_bvh2(const float *tri_pos, uint32_t n, uint32_t max_leaf_size, HostBVH &out);

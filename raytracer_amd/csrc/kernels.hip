@@ -845,7 +845,7 @@ constexpr int FAST_MIN_LANES = 16;
 #ifndef MIRT_FAST_ATTR
 #define MIRT_FAST_ATTR
 #endif
-template<bool ANY, bool COUNT>
+template<bool ANY, bool COUNT, int WIDTH>
 __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(TraceArgs a) {
   constexpr float NEAR = 1.0e-5f;
   constexpr float SLACK = 1.0f + 2.5e-5f;
@@ -866,10 +866,25 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(Trace
   uint32_t off_x = 0, off_y = 0, off_z = 0;               // 0: the near plane is the box minimum, 48: the maximum
   bool active = false;
   uint32_t cur = CHILD_EMPTY, tri_i = 0, tri_n = 0;
-  const uint32_t psz = ((total + WORK_PARTS - 1) / WORK_PARTS + 63u) & ~63u;
-  uint32_t chunk = (total / (gridDim.x * (TRACE_BLOCK / 64) * 4u)) & ~31u;
+  // Work distribution.  Device-scope atomics on one address retire at ~11 ns each no matter who issues them, so a scheme
+  // in which every one of the ~6000 waves touches a global counter even once costs ~70 us per launch.  Instead: the first
+  // static_16th/16 of the queue is cut into one slice per workgroup, handed out to its waves through an LDS counter; the
+  // rest is a pool of WORK_PARTS ranges with global counters that balances the load at the end, and a workgroup probes a
+  // dry range only once (LDS bitmask).
+  __shared__ uint32_t s_next, s_dry;
+  const uint32_t per_blk = (uint32_t) (((uint64_t) total * a.static_16th / 16u) / gridDim.x) & ~63u;
+  const uint32_t slice_end = (blockIdx.x + 1) * per_blk;
+  const uint32_t pool_lo = gridDim.x * per_blk, pool_total = total - pool_lo;
+  if (tid == 0) {
+    s_next = blockIdx.x * per_blk;
+    s_dry = 0;
+  }
+  __syncthreads();
+  const uint32_t psz = ((pool_total + WORK_PARTS - 1) / WORK_PARTS + 63u) & ~63u;     // pool positions per range
+  uint32_t chunk = (pool_total / (gridDim.x * (TRACE_BLOCK / 64) * 2u)) & ~31u;
   chunk = chunk < 32u ? 32u : (chunk > 256u ? 256u : chunk);
   uint32_t w_next = 0, w_end = 0, part = blockIdx.x & (WORK_PARTS - 1), parts_tried = 0;
+  bool slice_done = (per_blk == 0);
   bool wave_done = (total == 0);
   int sp = 0;
   uint32_t n_nodes = 0, n_tris = 0, n_node_steps = 0, n_tri_steps = 0;
@@ -899,25 +914,42 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(Trace
 
   while (true) {
     // ---------------------------------------------------------------- dynamic fetch (see k_trace4)
+    // (refilling costs ~150 instructions for the whole wave - normalise, three correctly rounded reciprocals - so it waits
+    // until enough lanes are idle to be worth it)
     const uint64_t need = __ballot(!active);
-    if (need != 0 && !wave_done) {
+    if (need != 0 && !wave_done && ((uint32_t) __popcll(need) >= a.refill_min || need == ~0ull)) {
       if (w_next >= w_end) {
-        while (parts_tried < (uint32_t) WORK_PARTS) {
-          // (peeking at the counter with an agent-scope load before the atomic was measured 20 % SLOWER overall)
+        if (!slice_done) {                                 // 1. the workgroup's own slice: LDS counter, no global traffic
           uint32_t got = 0;
-          if ((tid & 63) == 0) got = atomicAdd(a.work_head + CTR_STRIDE * part, chunk);
+          if ((tid & 63) == 0) got = atomicAdd(&s_next, 64u);
           got = __builtin_amdgcn_readfirstlane(got);
-          const uint32_t lo = part * psz + got;
-          if (got < psz && lo < total) {
-            const uint32_t hi_part = (part + 1) * psz < total ? (part + 1) * psz : total;
-            w_next = lo;
-            w_end = lo + chunk < hi_part ? lo + chunk : hi_part;
-            break;
+          if (got < slice_end) {
+            w_next = got;
+            w_end = got + 64u < slice_end ? got + 64u : slice_end;
+          } else {
+            slice_done = true;
           }
-          part = (part + 1) & (WORK_PARTS - 1);
-          parts_tried++;
         }
-        if (w_next >= w_end) wave_done = true;
+        if (w_next >= w_end) {                             // 2. the shared pool
+          while (parts_tried < (uint32_t) WORK_PARTS) {
+            if (!((*(volatile uint32_t *) &s_dry >> part) & 1u)) {
+              uint32_t got = 0;
+              if ((tid & 63) == 0) got = atomicAdd(a.work_head + CTR_STRIDE * part, chunk);
+              got = __builtin_amdgcn_readfirstlane(got);
+              const uint32_t lo = pool_lo + part * psz + got;
+              if (got < psz && lo < total) {
+                const uint32_t hi_part = pool_lo + (part + 1) * psz < total ? pool_lo + (part + 1) * psz : total;
+                w_next = lo;
+                w_end = lo + chunk < hi_part ? lo + chunk : hi_part;
+                break;
+              }
+              if ((tid & 63) == 0) atomicOr(&s_dry, 1u << part);     // tell the other waves of the workgroup
+            }
+            part = (part + 1) & (WORK_PARTS - 1);
+            parts_tried++;
+          }
+          if (w_next >= w_end) wave_done = true;
+        }
       }
       if (!wave_done) {
         if (!active) {
@@ -964,31 +996,74 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(Trace
     const int cn = __popcll(__ballot(at_node)), cl = __popcll(__ballot(active && !at_node));
     const bool run_nodes = cn > 0 && (cn >= (int) a.min_lanes || cn >= cl);
     if (run_nodes && at_node) {
-      const char *nb = (const char *) a.nodes4 + (size_t) cur * 128u;
       if (COUNT) {
         n_nodes++;
         if (lane_rank(__ballot(1)) == 0) n_node_steps++;
       }
-      const float4 NX = *(const float4 *) (nb + off_x), FX = *(const float4 *) (nb + (48u - off_x));
-      const float4 NY = *(const float4 *) (nb + 16u + off_y), FY = *(const float4 *) (nb + (64u - off_y));
-      const float4 NZ = *(const float4 *) (nb + 32u + off_z), FZ = *(const float4 *) (nb + (80u - off_z));
-      const float4 CHf = *(const float4 *) (nb + 96u);
-      const float nx[4] = {NX.x, NX.y, NX.z, NX.w}, ny[4] = {NY.x, NY.y, NY.z, NY.w}, nz[4] = {NZ.x, NZ.y, NZ.z, NZ.w};
-      const float fx[4] = {FX.x, FX.y, FX.z, FX.w}, fy[4] = {FY.x, FY.y, FY.z, FY.w}, fz[4] = {FZ.x, FZ.y, FZ.z, FZ.w};
-      uint32_t ch[4] = {f2u(CHf.x), f2u(CHf.y), f2u(CHf.z), f2u(CHf.w)};
-      float key[4];
-      const float far_limit = r.best_t;
+      if constexpr (WIDTH == 8) {
+        // 96-byte node: 8 children, 8-bit planes on a power-of-two grid anchored at the node's minimum corner p.
+        //   t = (p + q * 2^e - o) * inv = q * (2^e * inv) + (p - o) * inv : one cvt + one fma per plane
+        const uint4 *nq = (const uint4 *) ((const char *) a.nodes8 + (size_t) cur * 96u);
+        const uint4 H = nq[0], C0 = nq[1], C1 = nq[2], Q0 = nq[3], Q1 = nq[4], Q2 = nq[5];
+        const float sx = u2f((H.w & 0xFFu) << 23) * r.inv.x, sy = u2f(((H.w >> 8) & 0xFFu) << 23) * r.inv.y,
+                    sz = u2f(((H.w >> 16) & 0xFFu) << 23) * r.inv.z;
+        const float bx = (u2f(H.x) - r.o.x) * r.inv.x, by_ = (u2f(H.y) - r.o.y) * r.inv.y, bz_ = (u2f(H.z) - r.o.z) * r.inv.z;
+        const float ex = AXIS_EPS * fabsf(bx), ey = AXIS_EPS * fabsf(by_), ez = AXIS_EPS * fabsf(bz_);
+        const float cnx = bx - ex, cny = by_ - ey, cnz = bz_ - ez, cfx = bx + ex, cfy = by_ + ey, cfz = bz_ + ez;
+        const bool ngx = r.inv.x < 0, ngy = r.inv.y < 0, ngz = r.inv.z < 0;
+        // Q0 = qlo_x[8] qlo_y[8], Q1 = qlo_z[8] qhi_x[8], Q2 = qhi_y[8] qhi_z[8]; near plane = lo unless the ray runs backwards
+        const uint32_t nxw[2] = {ngx ? Q1.z : Q0.x, ngx ? Q1.w : Q0.y}, fxw[2] = {ngx ? Q0.x : Q1.z, ngx ? Q0.y : Q1.w};
+        const uint32_t nyw[2] = {ngy ? Q2.x : Q0.z, ngy ? Q2.y : Q0.w}, fyw[2] = {ngy ? Q0.z : Q2.x, ngy ? Q0.w : Q2.y};
+        const uint32_t nzw[2] = {ngz ? Q2.z : Q1.x, ngz ? Q2.w : Q1.y}, fzw[2] = {ngz ? Q1.x : Q2.z, ngz ? Q1.y : Q2.w};
+        const uint32_t ch[8] = {C0.x, C0.y, C0.z, C0.w, C1.x, C1.y, C1.z, C1.w};
+        const float far_limit = r.best_t;
+        uint32_t first = CHILD_EMPTY;
+        float first_key = MIRT_INF;
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const float tnx = fmaf(nx[c], r.inv.x, c_near.x), tny = fmaf(ny[c], r.inv.y, c_near.y), tnz = fmaf(nz[c], r.inv.z, c_near.z);
-        const float tfx = fmaf(fx[c], r.inv.x, c_far.x), tfy = fmaf(fy[c], r.inv.y, c_far.y), tfz = fmaf(fz[c], r.inv.z, c_far.z);
-        const float tmn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-        const float tmx = fminf(fminf(tfx, tfy), fminf(tfz, far_limit)) * SLACK;
-        const bool hit = (ch[c] != CHILD_EMPTY) && (tmn <= tmx) && (tmx > r.min_t);
-        key[c] = hit ? tmn : MIRT_INF;
-        if (!hit) ch[c] = CHILD_EMPTY;
-      }
-      if (!ANY) {
+        for (int c = 0; c < 8; c++) {
+          const int w = c >> 2, sh = 8 * (c & 3);
+          const float qnx = (float) ((nxw[w] >> sh) & 0xFFu), qny = (float) ((nyw[w] >> sh) & 0xFFu), qnz = (float) ((nzw[w] >> sh) & 0xFFu);
+          const float qfx = (float) ((fxw[w] >> sh) & 0xFFu), qfy = (float) ((fyw[w] >> sh) & 0xFFu), qfz = (float) ((fzw[w] >> sh) & 0xFFu);
+          const float tnx = fmaf(qnx, sx, cnx), tny = fmaf(qny, sy, cny), tnz = fmaf(qnz, sz, cnz);
+          const float tfx = fmaf(qfx, sx, cfx), tfy = fmaf(qfy, sy, cfy), tfz = fmaf(qfz, sz, cfz);
+          const float tmn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+          const float tmx = fminf(fminf(tfx, tfy), fminf(tfz, far_limit)) * SLACK;
+          const bool hit = (ch[c] != CHILD_EMPTY) && (tmn <= tmx) && (tmx > r.min_t);
+          if (hit) {
+            // the nearest child is entered next, the others wait on the stack with their entry distance
+            if (ANY ? (first == CHILD_EMPTY) : (tmn < first_key || first == CHILD_EMPTY)) {
+              if (first != CHILD_EMPTY) push(first, first_key);
+              first = ch[c];
+              first_key = tmn;
+            } else {
+              push(ch[c], tmn);
+            }
+          }
+        }
+        if (first != CHILD_EMPTY) enter(first);
+        else pop();
+      } else {
+        const char *nb = (const char *) a.nodes4 + (size_t) cur * 128u;
+        const float4 NX = *(const float4 *) (nb + off_x), FX = *(const float4 *) (nb + (48u - off_x));
+        const float4 NY = *(const float4 *) (nb + 16u + off_y), FY = *(const float4 *) (nb + (64u - off_y));
+        const float4 NZ = *(const float4 *) (nb + 32u + off_z), FZ = *(const float4 *) (nb + (80u - off_z));
+        const float4 CHf = *(const float4 *) (nb + 96u);
+        const float nx[4] = {NX.x, NX.y, NX.z, NX.w}, ny[4] = {NY.x, NY.y, NY.z, NY.w}, nz[4] = {NZ.x, NZ.y, NZ.z, NZ.w};
+        const float fx[4] = {FX.x, FX.y, FX.z, FX.w}, fy[4] = {FY.x, FY.y, FY.z, FY.w}, fz[4] = {FZ.x, FZ.y, FZ.z, FZ.w};
+        uint32_t ch[4] = {f2u(CHf.x), f2u(CHf.y), f2u(CHf.z), f2u(CHf.w)};
+        float key[4];
+        const float far_limit = r.best_t;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const float tnx = fmaf(nx[c], r.inv.x, c_near.x), tny = fmaf(ny[c], r.inv.y, c_near.y), tnz = fmaf(nz[c], r.inv.z, c_near.z);
+          const float tfx = fmaf(fx[c], r.inv.x, c_far.x), tfy = fmaf(fy[c], r.inv.y, c_far.y), tfz = fmaf(fz[c], r.inv.z, c_far.z);
+          const float tmn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+          const float tmx = fminf(fminf(tfx, tfy), fminf(tfz, far_limit)) * SLACK;
+          const bool hit = (ch[c] != CHILD_EMPTY) && (tmn <= tmx) && (tmx > r.min_t);
+          key[c] = hit ? tmn : MIRT_INF;
+          if (!hit) ch[c] = CHILD_EMPTY;
+        }
+        if (!ANY) {
 #define MIRT_CE(i, j)                                                         \
   {                                                                           \
     const bool sw = key[j] < key[i];                                          \
@@ -996,22 +1071,23 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(Trace
     const uint32_t ci = sw ? ch[j] : ch[i], cj = sw ? ch[i] : ch[j];          \
     key[i] = ki; key[j] = kj; ch[i] = ci; ch[j] = cj;                         \
   }
-        MIRT_CE(0, 1) MIRT_CE(2, 3) MIRT_CE(0, 2) MIRT_CE(1, 3) MIRT_CE(1, 2)
+          MIRT_CE(0, 1) MIRT_CE(2, 3) MIRT_CE(0, 2) MIRT_CE(1, 3) MIRT_CE(1, 2)
 #undef MIRT_CE
-      }
-      uint32_t first = CHILD_EMPTY;
-#pragma unroll
-      for (int c = 3; c >= 0; c--) {
-        if (ch[c] != CHILD_EMPTY) {
-          bool earlier = false;
-#pragma unroll
-          for (int e = 0; e < c; e++) earlier = earlier || (ch[e] != CHILD_EMPTY);
-          if (earlier) push(ch[c], key[c]);
-          else first = ch[c];
         }
+        uint32_t first = CHILD_EMPTY;
+#pragma unroll
+        for (int c = 3; c >= 0; c--) {
+          if (ch[c] != CHILD_EMPTY) {
+            bool earlier = false;
+#pragma unroll
+            for (int e = 0; e < c; e++) earlier = earlier || (ch[e] != CHILD_EMPTY);
+            if (earlier) push(ch[c], key[c]);
+            else first = ch[c];
+          }
+        }
+        if (first != CHILD_EMPTY) enter(first);
+        else pop();
       }
-      if (first != CHILD_EMPTY) enter(first);
-      else pop();
     }
 
     // ---------------------------------------------------------------- ... or a triangle (lanes that just reached a leaf join in)
@@ -1185,7 +1261,7 @@ size_t trace4_lds_bytes() { return (size_t) LDS_STACK * TRACE_BLOCK * sizeof(uin
 
 int trace4_blocks_per_cu() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_fast<false, false>, TRACE_BLOCK, trace4_lds_bytes()) != hipSuccess || nb < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_fast<false, false, 8>, TRACE_BLOCK, trace4_lds_bytes()) != hipSuccess || nb < 1)
     nb = 2;
   return nb;
 }
@@ -1201,14 +1277,24 @@ hipError_t launch_trace(const TraceArgs &a, bool any, uint32_t traversal, uint32
   } else {
     const size_t lds = trace4_lds_bytes();
     if (any && traversal == 0) {
-      if (a.count) k_trace_fast<true, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-      else k_trace_fast<true, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      if (a.width == 8) {
+        if (a.count) k_trace_fast<true, true, 8><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+        else k_trace_fast<true, false, 8><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      } else {
+        if (a.count) k_trace_fast<true, true, 4><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+        else k_trace_fast<true, false, 4><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      }
     } else if (any) {
       if (a.count) k_trace4<true, 1, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
       else k_trace4<true, 1, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
     } else if (traversal == 0) {
-      if (a.count) k_trace_fast<false, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-      else k_trace_fast<false, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      if (a.width == 8) {
+        if (a.count) k_trace_fast<false, true, 8><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+        else k_trace_fast<false, false, 8><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      } else {
+        if (a.count) k_trace_fast<false, true, 4><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+        else k_trace_fast<false, false, 4><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      }
     } else {
       if (a.count) k_trace4<false, 1, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
       else k_trace4<false, 1, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);

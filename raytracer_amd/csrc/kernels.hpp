@@ -50,6 +50,10 @@ struct RenderArgs {
 
 struct TraceArgs {
   const float4 *nodes4;                   // 8 float4 per wide node
+  const void *nodes8;                     // 96-byte quantised 8-wide nodes (k_trace_fast<.., 8>)
+  uint32_t refill_min;                    // k_trace_fast: idle lanes a wave collects before it fetches new rays
+  uint32_t static_16th;                   // k_trace_fast: sixteenths of the queue handed out as per-workgroup slices
+  uint32_t width;                         // k_trace_fast: 8 (default) or 4
   const float4 *nodes2;                   // 2 float4 per reference node
   const float4 *tris;                     // triangles in the order of the tree k_trace4 walks: p1, e1, e2, flat index
   const float4 *tris2;                    // triangles in the reference's flat order (k_trace2)
