@@ -96,6 +96,9 @@ typedef struct mirt_stats {
   uint64_t shadow_node_visits, shadow_tri_tests;
   /* wave-level loop steps behind those counts: visits / (64 * steps) = SIMD lane utilisation of that loop */
   uint64_t closest_node_steps, closest_tri_steps, shadow_node_steps, shadow_tri_steps;
+  /* the traversal that ran: opts->traversal, except that 0 becomes 1 for a scene whose own tree could not be built
+   * (non-finite vertex coordinates) */
+  uint32_t traversal_used, reserved;
 } mirt_stats;
 
 typedef struct mirt_scene mirt_scene;
@@ -113,6 +116,14 @@ const char *mirt_version(void);
 int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, uint32_t n_tris,
                       const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights, uint32_t n_lights,
                       uint32_t leaf_size, mirt_scene **out);
+
+/* The same with sphere primitives (scene/primitives.cuh:18-22, PrimitiveFactory::createSphere :184-190): prim_type holds
+ * the reference's enum per primitive (1 SPHERE, 2 TRIANGLE; NULL = all triangles).  A sphere's 9-float record in tri_pos is
+ * (origin.x, origin.y, origin.z, r, 5 unused); its tri_nrm record is ignored.  Replaces the SPHERE arms of
+ * Primitive::intersect / has_intersection / get_bbox (primitives.cuh:64-85, :111-136, :166-169). */
+int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, const uint8_t *prim_type,
+                            uint32_t n_prims, const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights,
+                            uint32_t n_lights, uint32_t leaf_size, mirt_scene **out);
 void mirt_scene_destroy(mirt_scene *scene);
 
 /* info[0..7]: bvh2 nodes, bvh2 depth (BVHAccel::get_max_depth, bvh.cuh:297), wide nodes, wide depth, n_tris, n_mats,
@@ -168,6 +179,14 @@ int mirt_tonemap_host(const float *rgb_in, uint32_t n_pixels, int32_t *rgb_out);
  * and nodes4_out (32 dwords per 128-byte wide node) may be NULL; call once with NULLs to size them. */
 int mirt_bvh_build_host(const float *tri_pos, uint32_t n_tris, uint32_t leaf_size, uint32_t counts[4],
                         uint32_t *nodes2_out, uint32_t *flat_to_orig, uint32_t *nodes4_out);
+
+/* The same for scenes with spheres (prim_type as in mirt_scene_create_prims), plus the ordered traversal's own tree:
+ * counts[8] = BVH2 nodes, BVH2 depth, wide nodes, wide depth, quantised 8-wide nodes, their depth, SAH 4-wide nodes, their
+ * depth; nodes8q_out: 24 dwords per 96-byte node (raytracer_amd/csrc/host_bvh.hpp Node8Q); fast_to_flat_out: that tree's
+ * primitive order -> flat index of the reference order.  Parity probe; no reference counterpart. */
+int mirt_bvh_build_host_prims(const float *prim_pos, const uint8_t *prim_type, uint32_t n_prims, uint32_t leaf_size,
+                              uint32_t counts[8], uint32_t *nodes2_out, uint32_t *flat_to_orig, uint32_t *nodes4_out,
+                              uint32_t *nodes8q_out, uint32_t *fast_to_flat_out);
 
 #ifdef __cplusplus
 }

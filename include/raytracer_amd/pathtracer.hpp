@@ -347,14 +347,22 @@ private:
     std::vector<uint32_t> mat;
     std::vector<mirt_bsdf> mats;
     std::unordered_map<const BSDF *, uint32_t> ids;          // one device record per distinct BSDF (bvh.cuh:123-137)
+    std::vector<uint8_t> ptype;
     for (const Primitive *p: primitives) {
-      if (p->type != Primitive::TRIANGLE) {
-        std::printf("sphere primitives are not supported by the MI355X path yet\n");
+      if (p->type == Primitive::SPHERE) {
+        const float rec[9] = {p->sphere.origin.x, p->sphere.origin.y, p->sphere.origin.z, p->sphere.r, 0, 0, 0, 0, 0};
+        pos.insert(pos.end(), rec, rec + 9);
+        nrm.insert(nrm.end(), 9, 0.f);
+        ptype.push_back(1);
+      } else if (p->type == Primitive::TRIANGLE) {
+        const Vector3f *v[6] = {&p->triangle.p1, &p->triangle.p2, &p->triangle.p3, &p->triangle.n1, &p->triangle.n2, &p->triangle.n3};
+        for (int k = 0; k < 3; k++) { pos.push_back(v[k]->x); pos.push_back(v[k]->y); pos.push_back(v[k]->z); }
+        for (int k = 3; k < 6; k++) { nrm.push_back(v[k]->x); nrm.push_back(v[k]->y); nrm.push_back(v[k]->z); }
+        ptype.push_back(2);
+      } else {
+        std::printf("INVALID primitive in the scene\n");
         return false;
       }
-      const Vector3f *v[6] = {&p->triangle.p1, &p->triangle.p2, &p->triangle.p3, &p->triangle.n1, &p->triangle.n2, &p->triangle.n3};
-      for (int k = 0; k < 3; k++) { pos.push_back(v[k]->x); pos.push_back(v[k]->y); pos.push_back(v[k]->z); }
-      for (int k = 3; k < 6; k++) { nrm.push_back(v[k]->x); nrm.push_back(v[k]->y); nrm.push_back(v[k]->z); }
       const BSDF *b = p->bsdf ? p->bsdf : &white_bsdf;
       auto it = ids.find(b);
       if (it == ids.end()) {
@@ -365,8 +373,9 @@ private:
     }
     std::vector<mirt_light> ls;
     for (const SceneLight &l: lights) ls.push_back(l.rec);
-    if (mirt_scene_create(pos.data(), nrm.data(), mat.data(), (uint32_t) mat.size(), mats.data(), (uint32_t) mats.size(),
-                          ls.data(), (uint32_t) ls.size(), parameters.bvh_node_size, &scene_) != MIRT_OK) {
+    if (mirt_scene_create_prims(pos.data(), nrm.data(), mat.data(), ptype.data(), (uint32_t) mat.size(), mats.data(),
+                                (uint32_t) mats.size(), ls.data(), (uint32_t) ls.size(), parameters.bvh_node_size,
+                                &scene_) != MIRT_OK) {
       std::printf("%s\n", mirt_last_error());
       return false;
     }

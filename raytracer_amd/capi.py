@@ -11,9 +11,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MIRT_LIB") or os.path.join(_HERE, "libmirt.so")   # MIRT_LIB: tuning builds (tools/build_variant.sh)
 
 SYMBOLS = [
-    "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_version", "mirt_scene_create", "mirt_scene_destroy",
+    "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_version", "mirt_scene_create", "mirt_scene_create_prims",
+    "mirt_scene_destroy",
     "mirt_scene_info", "mirt_scene_bvh2", "mirt_camera_look_at", "mirt_render", "mirt_render_accum", "mirt_tonemap",
     "mirt_primary_hits", "mirt_trace", "mirt_save_bmp", "mirt_tonemap_host", "mirt_bvh_build_host",
+    "mirt_bvh_build_host_prims",
 ]
 
 
@@ -56,7 +58,8 @@ class Stats(C.Structure):
                 ("shadow_launches", C.c_uint32), ("closest_node_visits", C.c_uint64), ("closest_tri_tests", C.c_uint64),
                 ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
                 ("closest_node_steps", C.c_uint64), ("closest_tri_steps", C.c_uint64),
-                ("shadow_node_steps", C.c_uint64), ("shadow_tri_steps", C.c_uint64)]
+                ("shadow_node_steps", C.c_uint64), ("shadow_tri_steps", C.c_uint64),
+                ("traversal_used", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -148,9 +151,15 @@ class Scene:
         self.mats = bsdf_records(sc.mats)
         self.lights = light_records(sc.lights)
         h = C.c_void_p()
-        _chk(lib.mirt_scene_create(_p(sc.pos), _p(sc.nrm), _p(sc.mat), C.c_uint32(sc.n), _p(self.mats),
-                                   C.c_uint32(len(self.mats)), _p(self.lights) if len(self.lights) else None,
-                                   C.c_uint32(len(self.lights)), C.c_uint32(leaf_size), C.byref(h)))
+        ptype = getattr(sc, "ptype", None)
+        if ptype is None:
+            _chk(lib.mirt_scene_create(_p(sc.pos), _p(sc.nrm), _p(sc.mat), C.c_uint32(sc.n), _p(self.mats),
+                                       C.c_uint32(len(self.mats)), _p(self.lights) if len(self.lights) else None,
+                                       C.c_uint32(len(self.lights)), C.c_uint32(leaf_size), C.byref(h)))
+        else:                                   # spheres: the reference's enum per primitive (1 SPHERE, 2 TRIANGLE)
+            _chk(lib.mirt_scene_create_prims(_p(sc.pos), _p(sc.nrm), _p(sc.mat), _p(ptype), C.c_uint32(sc.n), _p(self.mats),
+                                             C.c_uint32(len(self.mats)), _p(self.lights) if len(self.lights) else None,
+                                             C.c_uint32(len(self.lights)), C.c_uint32(leaf_size), C.byref(h)))
         self.h = h
         self.camera = None
         if sc.camera is not None:
@@ -244,17 +253,24 @@ class Scene:
         return (idx, tb, b) if bary else (idx, tb)
 
 
-def bvh_build_host(pos, leaf_size=4):
-    """Host-only structure probe (no GPU needed): the reference-layout BVH2, the flat order and the wide nodes."""
+def bvh_build_host(pos, leaf_size=4, ptype=None):
+    """Host-only structure probe (no GPU needed): the reference-layout BVH2, the flat order, the wide nodes, and the ordered
+    traversal's own quantised tree."""
     pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 9)
     n = len(pos)
-    cnt = (C.c_uint32 * 4)()
-    _chk(load().mirt_bvh_build_host(_p(pos), C.c_uint32(n), C.c_uint32(leaf_size), cnt, None, None, None))
+    pt = None if ptype is None else np.ascontiguousarray(ptype, np.uint8)
+    cnt = (C.c_uint32 * 8)()
+    f = load().mirt_bvh_build_host_prims
+    _chk(f(_p(pos), _p(pt), C.c_uint32(n), C.c_uint32(leaf_size), cnt, None, None, None, None, None))
     nodes2 = np.zeros((cnt[0], 8), np.uint32)
     flat = np.zeros(n, np.uint32)
     nodes4 = np.zeros((cnt[2], 32), np.uint32)
-    _chk(load().mirt_bvh_build_host(_p(pos), C.c_uint32(n), C.c_uint32(leaf_size), cnt, _p(nodes2), _p(flat), _p(nodes4)))
-    return dict(nodes2=nodes2, flat=flat, nodes4=nodes4, depth2=cnt[1], depth4=cnt[3])
+    nodes8q = np.zeros((cnt[4], 24), np.uint32)
+    fast_to_flat = np.zeros(n, np.uint32)
+    _chk(f(_p(pos), _p(pt), C.c_uint32(n), C.c_uint32(leaf_size), cnt, _p(nodes2), _p(flat), _p(nodes4), _p(nodes8q),
+           _p(fast_to_flat)))
+    return dict(nodes2=nodes2, flat=flat, nodes4=nodes4, depth2=cnt[1], depth4=cnt[3], nodes8q=nodes8q, depth8=cnt[5],
+                fast_to_flat=fast_to_flat)
 
 
 def tonemap(accum_ptr, w, h):

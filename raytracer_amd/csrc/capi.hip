@@ -206,17 +206,25 @@ void mirt_shutdown(void) {
 int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, uint32_t n_tris,
                       const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights, uint32_t n_lights,
                       uint32_t leaf_size, mirt_scene **out) {
+  return mirt_scene_create_prims(tri_pos, tri_nrm, tri_mat, nullptr, n_tris, mats, n_mats, lights, n_lights, leaf_size, out);
+}
+
+int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, const uint8_t *prim_type,
+                            uint32_t n_tris, const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights,
+                            uint32_t n_lights, uint32_t leaf_size, mirt_scene **out) {
   if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
   if (!out) return fail(MIRT_E_ARG, "out is null");
   *out = nullptr;
   if (!tri_pos || !tri_nrm || !tri_mat || n_tris == 0) return fail(MIRT_E_ARG, "SCENE NOT SET!");          // renderer.cuh:122
   if (!mats || n_mats == 0) return fail(MIRT_E_ARG, "no materials");
   if (n_lights && !lights) return fail(MIRT_E_ARG, "lights is null");
-  for (uint32_t i = 0; i < n_tris; i++)
+  for (uint32_t i = 0; i < n_tris; i++) {
     if (tri_mat[i] >= n_mats) return fail(MIRT_E_ARG, "material index out of range");
+    if (prim_type && prim_type[i] != 1 && prim_type[i] != 2) return fail(MIRT_E_ARG, "prim_type must be 1 (SPHERE) or 2 (TRIANGLE)");
+  }
   auto *s = new mirt_scene();
   try {
-    build_reference_bvh2(tri_pos, n_tris, leaf_size, s->bvh);
+    build_reference_bvh2(tri_pos, prim_type, n_tris, leaf_size, s->bvh);
     collapse_to_wide(s->bvh);
   } catch (const std::exception &ex) {
     delete s;
@@ -236,24 +244,39 @@ int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t
     const uint32_t o = s->bvh.flat_to_orig[f];
     const float *p = tri_pos + 9 * (size_t) o, *q = tri_nrm + 9 * (size_t) o;
     float *t = &tri[(size_t) f * 12], *m = &nrm[(size_t) f * 12];
-    t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
-    t[3] = p[3] - p[0]; t[4] = p[4] - p[1]; t[5] = p[5] - p[2];       // e1 = p2 - p1 (primitives.cuh:138)
-    t[6] = p[6] - p[0]; t[7] = p[7] - p[1]; t[8] = p[8] - p[2];       // e2 = p3 - p1 (primitives.cuh:139)
+    const uint32_t kind = (prim_type && prim_type[o] == 1) ? 1u : 0u;  // word 10 of both records: 0 triangle, 1 sphere
+    if (kind) {
+      t[0] = p[0]; t[1] = p[1]; t[2] = p[2];                          // origin
+      t[3] = p[3];                                                    // r
+      t[4] = p[3] * p[3];                                             // r2 = radius * radius (primitives.cuh:188)
+      t[5] = t[6] = t[7] = t[8] = 0.f;
+      memset(m, 0, 9 * sizeof(float));
+      m[0] = p[0]; m[1] = p[1]; m[2] = p[2];
+    } else {
+      t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
+      t[3] = p[3] - p[0]; t[4] = p[4] - p[1]; t[5] = p[5] - p[2];     // e1 = p2 - p1 (primitives.cuh:138)
+      t[6] = p[6] - p[0]; t[7] = p[7] - p[1]; t[8] = p[8] - p[2];     // e2 = p3 - p1 (primitives.cuh:139)
+      memcpy(m, q, 9 * sizeof(float));
+    }
     memcpy(t + 9, &f, 4);                                             // its own flat index (uniform with the fast tree's copy)
-    t[10] = t[11] = 0.f;
-    memcpy(m, q, 9 * sizeof(float));
+    memcpy(t + 10, &kind, 4);
+    t[11] = 0.f;
     memcpy(m + 9, &tri_mat[o], 4);
     memcpy(m + 10, &o, 4);
-    m[11] = 0.f;
+    memcpy(m + 11, &kind, 4);
   }
   // the ordered traversal's own tree (binned SAH) over the same triangles, in its own order
   std::vector<float> trif((size_t) n_tris * 12);
   {
     std::vector<float> flat_pos((size_t) n_tris * 9);
-    for (uint32_t f = 0; f < n_tris; f++)
+    std::vector<uint8_t> flat_type;
+    if (prim_type) flat_type.resize(n_tris);
+    for (uint32_t f = 0; f < n_tris; f++) {
       memcpy(&flat_pos[(size_t) f * 9], tri_pos + 9 * (size_t) s->bvh.flat_to_orig[f], 9 * sizeof(float));
+      if (prim_type) flat_type[f] = prim_type[s->bvh.flat_to_orig[f]];
+    }
     try {
-      build_fast_tree(flat_pos.data(), n_tris, s->bvh);
+      build_fast_tree(flat_pos.data(), prim_type ? flat_type.data() : nullptr, n_tris, s->bvh);
     } catch (const std::exception &) {
       s->fast_ok = false;
       s->bvh.nodes4f.clear();
@@ -672,6 +695,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     stats->closest_tri_steps = rs[9];
     stats->shadow_node_steps = rs[10];
     stats->shadow_tri_steps = rs[11];
+    stats->traversal_used = o.traversal;
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   }
   return MIRT_OK;
@@ -831,11 +855,29 @@ int mirt_save_bmp(const char *path, const int32_t *rgb, uint32_t width, uint32_t
 
 int mirt_bvh_build_host(const float *tri_pos, uint32_t n_tris, uint32_t leaf_size, uint32_t counts[4],
                         uint32_t *nodes2_out, uint32_t *flat_to_orig, uint32_t *nodes4_out) {
-  if (!tri_pos || !counts || n_tris == 0) return fail(MIRT_E_ARG, "null / empty argument");
+  uint32_t c8[8];
+  int rc = mirt_bvh_build_host_prims(tri_pos, nullptr, n_tris, leaf_size, c8, nodes2_out, flat_to_orig, nodes4_out, nullptr,
+                                     nullptr);
+  if (rc == MIRT_OK && counts) memcpy(counts, c8, 4 * sizeof(uint32_t));
+  return rc;
+}
+
+int mirt_bvh_build_host_prims(const float *prim_pos, const uint8_t *prim_type, uint32_t n_prims, uint32_t leaf_size,
+                              uint32_t counts[8], uint32_t *nodes2_out, uint32_t *flat_to_orig, uint32_t *nodes4_out,
+                              uint32_t *nodes8q_out, uint32_t *fast_to_flat_out) {
+  if (!prim_pos || !counts || n_prims == 0) return fail(MIRT_E_ARG, "null / empty argument");
   HostBVH b;
   try {
-    build_reference_bvh2(tri_pos, n_tris, leaf_size, b);
+    build_reference_bvh2(prim_pos, prim_type, n_prims, leaf_size, b);
     collapse_to_wide(b);
+    std::vector<float> flat_pos((size_t) n_prims * 9);
+    std::vector<uint8_t> flat_type;
+    if (prim_type) flat_type.resize(n_prims);
+    for (uint32_t f = 0; f < n_prims; f++) {
+      memcpy(&flat_pos[(size_t) f * 9], prim_pos + 9 * (size_t) b.flat_to_orig[f], 9 * sizeof(float));
+      if (prim_type) flat_type[f] = prim_type[b.flat_to_orig[f]];
+    }
+    build_fast_tree(flat_pos.data(), prim_type ? flat_type.data() : nullptr, n_prims, b);
   } catch (const std::exception &ex) {
     return fail(MIRT_E_LIMIT, ex.what());
   }
@@ -843,9 +885,15 @@ int mirt_bvh_build_host(const float *tri_pos, uint32_t n_tris, uint32_t leaf_siz
   counts[1] = b.depth2;
   counts[2] = (uint32_t) b.nodes4.size();
   counts[3] = b.depth4;
+  counts[4] = (uint32_t) (b.nodes8q.size() / (sizeof(Node8Q) / 4));
+  counts[5] = b.depth8;
+  counts[6] = (uint32_t) b.nodes4f.size();
+  counts[7] = b.depth4f;
   if (nodes2_out) memcpy(nodes2_out, b.nodes2.data(), b.nodes2.size() * sizeof(Node2));
   if (flat_to_orig) memcpy(flat_to_orig, b.flat_to_orig.data(), b.flat_to_orig.size() * 4);
   if (nodes4_out) memcpy(nodes4_out, b.nodes4.data(), b.nodes4.size() * sizeof(Node4));
+  if (nodes8q_out) memcpy(nodes8q_out, b.nodes8q.data(), b.nodes8q.size() * 4);
+  if (fast_to_flat_out) memcpy(fast_to_flat_out, b.fast_to_flat.data(), b.fast_to_flat.size() * 4);
   return MIRT_OK;
 }
 

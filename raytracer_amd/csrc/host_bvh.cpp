@@ -3,6 +3,7 @@
 #include "host_bvh.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -20,6 +21,7 @@ struct Box {
 
 struct Builder {
   const float *pos;
+  const uint8_t *ptype = nullptr;
   uint32_t max_leaf;
   std::vector<Box> pbox;                // per input triangle (primitives.cuh:170-175)
   std::vector<float> pcent;             // centroid per triangle x3 (bbox.cuh:48-50)
@@ -39,15 +41,22 @@ struct Builder {
     for (uint32_t i = 0; i < n; i++) {
       const float *p = pos + 9 * (size_t) i;
       Box b;
-      for (int a = 0; a < 3; a++) {
-        b.lo[a] = p[a];
-        b.hi[a] = p[a];                                 // BBox(p1)
-      }
-      for (int v = 1; v < 3; v++)
-        for (int a = 0; a < 3; a++) {                    // expand(p2), expand(p3)   bbox.cuh:38-46
-          b.lo[a] = minf(b.lo[a], p[3 * v + a]);
-          b.hi[a] = maxf(b.hi[a], p[3 * v + a]);
+      if (ptype && ptype[i] == 1) {                      // SPHERE: origin -/+ (r, r, r)   primitives.cuh:166-169
+        for (int a = 0; a < 3; a++) {
+          b.lo[a] = p[a] - p[3];
+          b.hi[a] = p[a] + p[3];
         }
+      } else {
+        for (int a = 0; a < 3; a++) {
+          b.lo[a] = p[a];
+          b.hi[a] = p[a];                               // BBox(p1)
+        }
+        for (int v = 1; v < 3; v++)
+          for (int a = 0; a < 3; a++) {                  // expand(p2), expand(p3)   bbox.cuh:38-46
+            b.lo[a] = minf(b.lo[a], p[3 * v + a]);
+            b.hi[a] = maxf(b.hi[a], p[3 * v + a]);
+          }
+      }
       pbox[i] = b;
       const float rc = (float) (1.0 / (double) 2.0f);    // Vector3f::operator/(float)  Vector3f.cuh:106-109
       for (int a = 0; a < 3; a++) pcent[3 * (size_t) i + a] = rc * (b.lo[a] + b.hi[a]);
@@ -230,11 +239,12 @@ struct Collapser {
 
 }  // namespace
 
-void build_reference_bvh2(const float *tri_pos, uint32_t n, uint32_t max_leaf_size, HostBVH &out) {
+void build_reference_bvh2(const float *tri_pos, const uint8_t *prim_type, uint32_t n, uint32_t max_leaf_size, HostBVH &out) {
   if (n == 0) throw std::runtime_error("scene has no triangles");
   if (n >= (1u << LEAF_COUNT_SHIFT)) throw std::runtime_error("more than 2^27-1 triangles");
   Builder bd;
   bd.pos = tri_pos;
+  bd.ptype = prim_type;
   bd.max_leaf = max_leaf_size;
   bd.prepare(n);
   bd.tree.reserve((size_t) n);
@@ -265,7 +275,8 @@ void collapse_to_wide(HostBVH &bvh) {
 namespace {
 
 struct SahBuilder {
-  const float *pos;                       // triangles in FLAT order, 9 floats each
+  const float *pos;                       // primitives in FLAT order, 9 floats each
+  const uint8_t *ptype = nullptr;
   std::vector<Box> pbox;
   std::vector<float> cent;
   std::vector<uint32_t> order;
@@ -302,11 +313,19 @@ struct SahBuilder {
     for (uint32_t i = 0; i < n; i++) {
       const float *p = pos + 9 * (size_t) i;
       Box b = empty();
-      for (int v = 0; v < 3; v++)
+      if (ptype && ptype[i] == 1) {
+        // sphere: one ulp of room on each side (the intersector's t is not computed from these planes)
         for (int k = 0; k < 3; k++) {
-          b.lo[k] = std::fmin(b.lo[k], p[3 * v + k]);
-          b.hi[k] = std::fmax(b.hi[k], p[3 * v + k]);
+          b.lo[k] = std::nextafter(p[k] - p[3], -std::numeric_limits<float>::infinity());
+          b.hi[k] = std::nextafter(p[k] + p[3], std::numeric_limits<float>::infinity());
         }
+      } else {
+        for (int v = 0; v < 3; v++)
+          for (int k = 0; k < 3; k++) {
+            b.lo[k] = std::fmin(b.lo[k], p[3 * v + k]);
+            b.hi[k] = std::fmax(b.hi[k], p[3 * v + k]);
+          }
+      }
       pbox[i] = b;
       for (int k = 0; k < 3; k++) cent[3 * (size_t) i + k] = 0.5f * (b.lo[k] + b.hi[k]);
       order[i] = i;
@@ -451,22 +470,29 @@ struct Collapser8 {
       eb[a] = e + 127;
       step[a] = std::ldexp(1.0, e);
     }
-    q.exps = (uint32_t) eb[0] | ((uint32_t) eb[1] << 8) | ((uint32_t) eb[2] << 16);
     uint8_t *qlo[3] = {q.qlo_x, q.qlo_y, q.qlo_z}, *qhi[3] = {q.qhi_x, q.qhi_y, q.qhi_z};
-    for (int k = 0; k < nk; k++) {
-      const Node2 &c = n2[kids[k]];
-      for (int a = 0; a < 3; a++) {
-        double lo = std::floor(((double) c.minp[a] - (double) q.p[a]) / step[a]);
-        double hi = std::ceil(((double) c.maxp[a] - (double) q.p[a]) / step[a]);
-        if (lo < 0) lo = 0;
-        if (hi > 255) hi = 255;
-        // exact in double: p + q * 2^e.  The quantised box must contain the child's box.
-        if ((double) q.p[a] + lo * step[a] > (double) c.minp[a] || (double) q.p[a] + hi * step[a] < (double) c.maxp[a])
-          throw std::runtime_error("quantised child box does not contain the exact one");
-        qlo[a][k] = (uint8_t) lo;
-        qhi[a][k] = (uint8_t) hi;
+    for (int a = 0; a < 3; a++) {
+      for (;;) {                                          // (a second pass only when rounding pushes a plane past 255)
+        bool fits = true;
+        for (int k = 0; k < nk && fits; k++) {
+          const Node2 &c = n2[kids[k]];
+          const double p = (double) q.p[a], cmin = (double) c.minp[a], cmax = (double) c.maxp[a];
+          double lo = std::floor((cmin - p) / step[a]);
+          double hi = std::ceil((cmax - p) / step[a]);
+          if (lo < 0) lo = 0;
+          // p + q * 2^e is exact in double; the quotient above is not when the operands differ by more than 2^53
+          while (lo > 0 && p + lo * step[a] > cmin) lo -= 1;
+          while (p + hi * step[a] < cmax) hi += 1;
+          if (hi > 255 || p + lo * step[a] > cmin) { fits = false; break; }
+          qlo[a][k] = (uint8_t) lo;
+          qhi[a][k] = (uint8_t) hi;
+        }
+        if (fits) break;
+        if (++eb[a] > 254) throw std::runtime_error("scene extent too large for the quantised tree");
+        step[a] *= 2.0;
       }
     }
+    q.exps = (uint32_t) eb[0] | ((uint32_t) eb[1] << 8) | ((uint32_t) eb[2] << 16);
     out[id] = q;
     for (int k = 0; k < nk; k++) {
       const Node2 &c = n2[kids[k]];
@@ -484,13 +510,14 @@ struct Collapser8 {
   }
 };
 
-void build_fast_tree(const float *tri_pos_flat, uint32_t n, HostBVH &bvh) {
+void build_fast_tree(const float *tri_pos_flat, const uint8_t *prim_type_flat, uint32_t n, HostBVH &bvh) {
   std::vector<Node2> n2;
   n2.reserve((size_t) n);
   bvh.fast_to_flat.clear();
   bvh.fast_to_flat.reserve(n);
   SahBuilder sb(n2, bvh.fast_to_flat);
   sb.pos = tri_pos_flat;
+  sb.ptype = prim_type_flat;
   sb.max_leaf = 3;                                         // measured best of 1..8 on the bench workload (tools/sweep.sh MIRT_FAST_LEAF)
   if (const char *e = std::getenv("MIRT_FAST_LEAF")) {     // tuning knob (1..15: the inline leaf count field)
     int v = std::atoi(e);

@@ -64,10 +64,11 @@ struct Node8Q {
 };
 static_assert(sizeof(Node8Q) == 96, "Node8Q layout");
 
-// tri_pos: n x 9 floats.  Throws std::runtime_error on limits.
-void build_reference_bvh2(const float *tri_pos, uint32_t n, uint32_t max_leaf_size, HostBVH &out);
+// prim_pos: n x 9 floats (triangle: p1 p2 p3; sphere: centre, radius, 5 unused); prim_type: NULL (all triangles) or one
+// byte per primitive with the reference's enum (1 SPHERE, 2 TRIANGLE, primitives.cuh:11-15).  Throws on limits.
+void build_reference_bvh2(const float *prim_pos, const uint8_t *prim_type, uint32_t n, uint32_t max_leaf_size, HostBVH &out);
 void collapse_to_wide(HostBVH &bvh);
-// tri_pos_flat: the triangles in the reference's flat order (n x 9 floats)
-void build_fast_tree(const float *tri_pos_flat, uint32_t n, HostBVH &bvh);
+// prim_pos_flat / prim_type_flat: the primitives in the reference's flat order
+void build_fast_tree(const float *prim_pos_flat, const uint8_t *prim_type_flat, uint32_t n, HostBVH &bvh);
 
 }  // namespace mirt

@@ -247,8 +247,11 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
         const float by = h.y, bz = h.z;
         const float bx = 1 - by - bz;                       // primitives.cuh:147
         DIsect is;
-        is.normal = vadd(vadd(vlscale(bx, mk(n0.x, n0.y, n0.z)), vlscale(by, mk(n0.w, n1.x, n1.y))),
-                         vlscale(bz, mk(n1.z, n1.w, n2.x)));           // primitives.cuh:156
+        if (f2u(n2.w) != 0u)                                           // sphere: (o + max_t * d) - origin, primitives.cuh:134
+          is.normal = vsub(vadd(origin, vlscale(h.x, direction)), mk(n0.x, n0.y, n0.z));
+        else
+          is.normal = vadd(vadd(vlscale(bx, mk(n0.x, n0.y, n0.z)), vlscale(by, mk(n0.w, n1.x, n1.y))),
+                           vlscale(bz, mk(n1.z, n1.w, n2.x)));         // primitives.cuh:156
         isect_compute(is, origin, direction, h.x);
         if (bsdf.type == BSDF_EMISSION) total = vadd(total, vmul(mask, mk(bsdf.p[0], bsdf.p[1], bsdf.p[2])));
         else total = vadd(total, vmul(mask, mk(0, 0, 0)));  // raytracer.cuh:65 (keeps inf/NaN * 0 semantics)
@@ -418,13 +421,37 @@ __device__ __forceinline__ void load_ray(const TraceArgs &a, uint32_t id, LaneRa
   r.id = id;
 }
 
+// Sphere arm of Primitive::intersect / has_intersection (primitives.cuh:64-85, :111-136).  The two differ only in an
+// extra reject clause of the shadow version (:76) that the closest-hit version reaches two lines later (:128), so one
+// function serves both: `cand` = everything but the comparison against max_t, `t` = the root the reference would keep.
+struct SphereHit { bool geometric, cand; float t, t0, t1; };
+__device__ __forceinline__ SphereHit sphere_eval(const float4 q0, const float4 q1, const LaneRay &r) {
+  const V3 a = vsub(mk(q0.x, q0.y, q0.z), r.o);
+  const float b = vdot(a, r.d);
+  const float c = vdot(a, a) - b * b;
+  const float r2 = q1.x;
+  SphereHit h;
+  h.geometric = !(b < 0) && !(c > r2);
+  const float disc = sqrtf(r2 - c);
+  h.t0 = b - disc;
+  h.t1 = b + disc;
+  h.t = (h.t0 > r.min_t) ? h.t0 : h.t1;
+  h.cand = h.geometric && !(h.t1 <= r.min_t);
+  return h;
+}
+
 // Moeller-Trumbore exactly as primitives.cuh:137-158 evaluates it (e1, e2 are stored: same subtraction, same bits).
-// Returns the reference's accept decision against `max_t`.
+// Returns the reference's accept decision against `max_t`.  Word 10 of the record: 0 triangle, 1 sphere.
 __device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const LaneRay &r, float max_t, float &t,
                                          float &by, float &bz, uint32_t &flat) {
   const float4 q0 = tris[3 * (size_t) idx], q1 = tris[3 * (size_t) idx + 1], q2 = tris[3 * (size_t) idx + 2];
+  flat = f2u(q2.y);                   // index of this primitive in the reference's flat order
+  if (f2u(q2.z) != 0u) {
+    const SphereHit h = sphere_eval(q0, q1, r);
+    t = h.t; by = 0.f; bz = 0.f;
+    return h.cand && !(h.t > max_t);
+  }
   const V3 p1 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
-  flat = f2u(q2.y);                   // index of this triangle in the reference's flat order
   const V3 s = vsub(r.o, p1);
   const V3 s1 = vcross(r.d, e2);
   const V3 s2 = vcross(s, e1);
@@ -436,15 +463,23 @@ __device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const
   return !(t < 0 || t <= r.min_t || t > max_t || bx < 0 || by < 0 || bz < 0);
 }
 
-// The ordered traversal's variant: same arithmetic and accept decision, plus `near`: the triangle is hit inside its
-// edges at a distance within NEAR (relative) of one of the two limits the accept test compares against.  For such a hit
-// the reference's own outcome hangs on whether ITS leaf box passed `tmin <= tmax` (bbox.cuh:77) in the last ulps, which
-// no other tree can know: the caller hands the ray to the reference walk (k_trace2).
+// The ordered traversal's variant: same arithmetic and accept decision, plus `near`: the primitive is hit (a triangle
+// inside its edges, a sphere at either root) at a distance within NEAR (relative) of one of the two limits the accept test
+// compares against.  For such a hit the reference's own outcome hangs on whether ITS leaf box passed `tmin <= tmax`
+// (bbox.cuh:77) in the last ulps, which no other tree can know: the caller hands the ray to the reference walk (k_redo).
 __device__ __forceinline__ bool tri_test_near(const float4 *tris, uint32_t idx, const LaneRay &r, float max_t, float near_rel,
                                               float &t, float &by, float &bz, uint32_t &flat, bool &near) {
   const float4 q0 = tris[3 * (size_t) idx], q1 = tris[3 * (size_t) idx + 1], q2 = tris[3 * (size_t) idx + 2];
-  const V3 p1 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
   flat = f2u(q2.y);
+  if (f2u(q2.z) != 0u) {
+    const SphereHit h = sphere_eval(q0, q1, r);
+    t = h.t; by = 0.f; bz = 0.f;
+    const float b0 = near_rel * fabsf(h.t0), b1 = near_rel * fabsf(h.t1);
+    near = h.geometric && (fabsf(h.t0 - max_t) <= b0 || fabsf(h.t0 - r.min_t) <= b0 ||
+                           fabsf(h.t1 - max_t) <= b1 || fabsf(h.t1 - r.min_t) <= b1);
+    return h.cand && !(h.t > max_t);
+  }
+  const V3 p1 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
   const V3 s = vsub(r.o, p1);
   const V3 s1 = vcross(r.d, e2);
   const V3 s2 = vcross(s, e1);

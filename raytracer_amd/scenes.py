@@ -104,7 +104,7 @@ class SceneData:
     mats: np.ndarray
     lights: np.ndarray
     camera: Camera
-    ptype: np.ndarray | None = None      # only the oracle/ref accept spheres (ptype == 1)
+    ptype: np.ndarray | None = None      # the reference's enum per primitive: 1 SPHERE (pos = centre, radius), 2 TRIANGLE
 
     @property
     def n(self):
@@ -276,7 +276,7 @@ def mtl_materials(name):
 
 # --------------------------------------------------------------------------------------- scenes
 def known_answer_scene():
-    """SURVEY.md 8(c) known-answer scene (sphere + floor, 64x48, checksum 950192).  Has a sphere: CPU checkers only."""
+    """SURVEY.md 8(c) known-answer scene (sphere + floor, 64x48, checksum 950192)."""
     pos = np.zeros((3, 9), np.float32)
     nrm = np.zeros((3, 9), np.float32)
     pos[0, :4] = [0, 1, 0, 1]
@@ -410,6 +410,25 @@ def random_soup(n, seed=0, extent=1.0, tri_size=0.15, n_mats=3):
     return SceneData(f"soup{n}", pos.reshape(n, 9), nrm.reshape(n, 9), rng.integers(0, n_mats, n), mats,
                      np.array([point_light((3, 3, 3), (0, 3, 0))]),
                      Camera((0, 0.5, -3.5), (0, 0, 0), hfov=42, vfov=42)).finalize()
+
+
+def sphere_soup(n_tri=300, n_sph=60, seed=3):
+    """Triangle soup + spheres (the reference's second primitive type): overlapping spheres, an exact duplicate (tie rule),
+    spheres around the camera-side origins of the parity rays."""
+    rng = np.random.default_rng(seed)
+    t = random_soup(n_tri, seed)
+    sp = np.zeros((n_sph, 9), np.float32)
+    sp[:, :3] = rng.uniform(-1.0, 1.0, (n_sph, 3))
+    sp[:, 3] = rng.uniform(0.03, 0.35, n_sph)
+    sp[1] = sp[0]
+    sp[2, :3] = sp[3, :3]                      # concentric
+    pos = np.concatenate([t.pos, sp])
+    nrm = np.concatenate([t.nrm, np.zeros((n_sph, 9), np.float32)])
+    mat = np.concatenate([t.mat, rng.integers(0, len(t.mats), n_sph).astype(np.uint32)])
+    ptype = np.concatenate([np.full(n_tri, 2, np.uint8), np.full(n_sph, 1, np.uint8)])
+    perm = rng.permutation(n_tri + n_sph)
+    return SceneData(f"sphere_soup{n_tri}_{n_sph}", pos[perm], nrm[perm], mat[perm], t.mats, t.lights, t.camera,
+                     ptype=ptype[perm]).finalize()
 
 
 WORKLOADS = {

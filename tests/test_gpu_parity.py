@@ -23,6 +23,7 @@ SCENES = {
     "conf20k": lambda: scenes.conference_scene(20000),
     "adaptive": lambda: scenes.cornell_scene(1, "diffuse"),
 }
+SPHERE_SCENES = {"sphere_soup": lambda: scenes.sphere_soup(300, 60, 3), "known_answer": scenes.known_answer_scene}
 
 
 def random_rays(sc, n, seed, unit):
@@ -75,9 +76,9 @@ def test_primary_hits_full_size_vs_oracle(mirt, oracle):
     s.close()
 
 
-@pytest.mark.parametrize("key", ["cornell_mixed", "soup500", "conf20k"])
+@pytest.mark.parametrize("key", ["cornell_mixed", "soup500", "conf20k", "sphere_soup", "known_answer"])
 def test_trace_arbitrary_rays(mirt, oracle, key):
-    sc = SCENES[key]()
+    sc = (SCENES.get(key) or SPHERE_SCENES[key])()
     oracle.load(sc)
     s = mirt.Scene(sc)
     for unit in (False, True):
@@ -92,6 +93,35 @@ def test_trace_arbitrary_rays(mirt, oracle, key):
             if trav != 0:
                 assert (ht == at).all()          # which primitive ends an any-hit walk is order dependent in mode 0
         assert (ci >= 0).sum() > 1000 and (ci < 0).sum() > 100
+    s.close()
+
+
+def test_known_answer_scene_with_a_sphere(mirt, oracle, golden):
+    """sphere + floor, Parameters{4,1,64,0.05,4,4}, 64x48; the reference's film sums to 950192.  Sphere
+    primitives (primitives.cuh:64-85, :111-136) through the same kernels: hits bit-exact, film within the libm bar."""
+    g = golden("known_answer")
+    sc = scenes.known_answer_scene()
+    s = mirt.Scene(sc)
+    for trav in (0, 1, 2):
+        idx, tb = s.primary_hits(64, 48, traversal=trav)
+        assert (idx == g["hit_idx"]).all() and (tb == g["hit_tbits"]).all(), f"traversal {trav}"
+    for trav in (0, 1):
+        img = s.render(64, 48, spp=4, spl=1, batch=64, tol=0.05, depth=4, traversal=trav)
+        assert (img == g["rgb"]).mean() >= 0.999, f"only {(img == g['rgb']).mean():.5f} of the film bytes are identical"
+        assert abs(int(img.sum()) - int(g["checksum"])) <= 0.001 * int(g["checksum"])
+    s.close()
+    # a mixed scene: primary hits against the oracle in every traversal
+    sc = scenes.sphere_soup(300, 60, 3)
+    oracle.load(sc)
+    oi, ot = oracle.primary_hits(160, 120)
+    s = mirt.Scene(sc)
+    for trav in (0, 1, 2):
+        gi, gt = s.primary_hits(160, 120, traversal=trav)
+        assert (gi == oi).all() and (gt == ot).all(), f"traversal {trav}: {(gi != oi).sum()} differ"
+    assert len(np.unique(oi)) > 50
+    img = s.render(160, 120, spp=4, spl=1, batch=64, tol=0.0, depth=4)
+    ref = oracle.render(160, 120, spp=4, spl=1, batch=64, tol=0.0, depth=4)
+    assert (img == ref).mean() >= 0.999
     s.close()
 
 
@@ -134,6 +164,7 @@ def test_film_reference_rng_vs_reference_golden(mirt, golden, key):
         assert (d == 0).mean() >= 0.999, f"{key}: only {(d == 0).mean():.5f} of the film bytes are identical"
         assert abs(img.mean() - g[key + "_rgb_fabs"].mean()) < 0.05
         assert s.last["tonemap_table_exact"] == 1
+        assert s.last["traversal_used"] == trav           # the scene's own tree was built: no silent fallback to mode 1
     # the g++ build's integer abs() in GLASS, behind its option
     img = s.render(w, h, spp=spp, spl=spl, batch=batch, tol=tol, depth=depth, glass_int_abs=1)
     assert (img == g[key + "_rgb"]).mean() >= 0.999
