@@ -10,7 +10,7 @@ over RCCL; the only collective is the sum-reduce of the accumulation buffer.
     python bench.py [--gpus N --steps K --warmup W]       # N > 1: launched under torch.distributed.run by the driver
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the closest-hit wide-BVH traversal) against HBM
-peak: algorithmic bytes = rays x (160 B of wavefront state + node visits x 128 B + triangle tests x 48 B),
+peak: algorithmic bytes = rays x (160 B of wavefront state + node visits x 96 B + triangle tests x 48 B),
 time = that kernel's launches measured with HIP events on its own stream inside the timed steps.  `cpu_baseline` times the
 reference's own CPU path (oracle/_ref, built from /root/reference in the build container) -- or the C oracle when that
 library is absent -- on a bounded crop of the same workload, on the box's host cores.
@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 B_STATE_CLOSEST = 160          # ray r/w 64 + hit r/w 32 + path state r/w 64
-S_NODE = 128                   # bytes of one wide node
+S_NODE = {0: 96, 1: 128, 2: 32}  # bytes of one node: quantised 8-wide (traversal 0), 4-wide (1), reference BVH2 (2)
 S_TRI = 48                     # bytes of one packed triangle (p1, e1, e2)
 
 
@@ -167,7 +167,7 @@ def main():
                                  depth=args.depth, **{**opt, "count": True, "sample_count": 0, "sample_begin": 0})
         n_node = cnt["closest_node_visits"] / max(1, cnt["closest_rays"])
         n_tri = cnt["closest_tri_tests"] / max(1, cnt["closest_rays"])
-        b_ray = B_STATE_CLOSEST + n_node * S_NODE + n_tri * S_TRI
+        b_ray = B_STATE_CLOSEST + n_node * S_NODE[args.traversal] + n_tri * S_TRI
         launches = sum(s["closest_launches"] for s in stats)
         k_ms = sum(s["trace_closest_ms"] for s in stats)
         k_rays = sum(s["closest_rays"] for s in stats)

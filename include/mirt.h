@@ -181,8 +181,7 @@ int mirt_bvh_build_host(const float *tri_pos, uint32_t n_tris, uint32_t leaf_siz
                         uint32_t *nodes2_out, uint32_t *flat_to_orig, uint32_t *nodes4_out);
 
 /* The same for scenes with spheres (prim_type as in mirt_scene_create_prims), plus the ordered traversal's own tree:
- * counts[8] = BVH2 nodes, BVH2 depth, wide nodes, wide depth, quantised 8-wide nodes, their depth, SAH 4-wide nodes, their
- * depth; nodes8q_out: 24 dwords per 96-byte node (raytracer_amd/csrc/host_bvh.hpp Node8Q); fast_to_flat_out: that tree's
+ * counts[8] = BVH2 nodes, BVH2 depth, wide nodes, wide depth, quantised 8-wide nodes, their depth, 0, 0; nodes8q_out: 24 dwords per 96-byte node (raytracer_amd/csrc/host_bvh.hpp Node8Q); fast_to_flat_out: that tree's
  * primitive order -> flat index of the reference order.  Parity probe; no reference counterpart. */
 int mirt_bvh_build_host_prims(const float *prim_pos, const uint8_t *prim_type, uint32_t n_prims, uint32_t leaf_size,
                               uint32_t counts[8], uint32_t *nodes2_out, uint32_t *flat_to_orig, uint32_t *nodes4_out,

@@ -62,8 +62,6 @@ struct Global {
   int device = -1;
   int n_cu = 0;
   int blocks_per_cu = 2;
-  uint32_t min_lanes = 16;
-  uint32_t fast_width = 8;
   uint32_t refill_min = 8;
   bool serial = false;
   uint32_t static_16th = 12;
@@ -108,15 +106,16 @@ struct mirt_scene {
   HostBVH bvh;
   uint32_t n_tris = 0, n_mats = 0, n_lights = 0;
   bool has_microfacet = false;
+  bool has_spheres = false;
   bool fast_ok = true;                   // false: the SAH tree could not be built (non-finite vertices): traversal 0 runs as 1
-  DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big, nodes4f, trisf, nodes8q;
+  DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big, trisf, nodes8q;
   uint32_t ovf_depth = 0;
   uint32_t trace_threads = 0;
   // work buffers (sized per render)
   DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2], mf_queue;
   DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t;
   size_t device_bytes() const {
-    const DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &nodes4f, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
+    const DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                            &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0],
                            &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue};
     size_t s = 0;
@@ -124,7 +123,7 @@ struct mirt_scene {
     return s;
   }
   void release_all() {
-    DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &nodes4f, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
+    DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                      &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0], &redo_q[1],
                      &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue};
     for (auto *b: all) b->release();
@@ -165,7 +164,6 @@ int mirt_init(int device) {
     int v = atoi(s);
     if (v >= 1 && v <= 16) G.blocks_per_cu = v;
   }
-  if (const char *s = getenv("MIRT_FAST_WIDTH")) G.fast_width = atoi(s) == 4 ? 4u : 8u;
   if (const char *s = getenv("MIRT_SERIAL")) G.serial = atoi(s) != 0;
   if (const char *s = getenv("MIRT_STATIC_16TH")) {
     int v = atoi(s);
@@ -174,10 +172,6 @@ int mirt_init(int device) {
   if (const char *s = getenv("MIRT_REFILL_MIN")) {
     int v = atoi(s);
     if (v >= 1 && v <= 64) G.refill_min = (uint32_t) v;
-  }
-  if (const char *s = getenv("MIRT_MIN_LANES")) {
-    int v = atoi(s);
-    if (v >= 0 && v <= 64) G.min_lanes = (uint32_t) v;
   }
   G.device = device;
   G.ready = true;
@@ -245,6 +239,7 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
     const float *p = tri_pos + 9 * (size_t) o, *q = tri_nrm + 9 * (size_t) o;
     float *t = &tri[(size_t) f * 12], *m = &nrm[(size_t) f * 12];
     const uint32_t kind = (prim_type && prim_type[o] == 1) ? 1u : 0u;  // word 10 of both records: 0 triangle, 1 sphere
+    if (kind) s->has_spheres = true;
     if (kind) {
       t[0] = p[0]; t[1] = p[1]; t[2] = p[2];                          // origin
       t[3] = p[3];                                                    // r
@@ -279,9 +274,8 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
       build_fast_tree(flat_pos.data(), prim_type ? flat_type.data() : nullptr, n_tris, s->bvh);
     } catch (const std::exception &) {
       s->fast_ok = false;
-      s->bvh.nodes4f.clear();
       s->bvh.nodes8q.clear();
-      s->bvh.depth4f = s->bvh.depth8 = 0;
+      s->bvh.depth8 = 0;
     }
     if (s->fast_ok)
       for (uint32_t j = 0; j < n_tris; j++)
@@ -301,8 +295,6 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
   bool ok = up(s->tris, tri.data(), tri.size() * 4) && up(s->tri_nrm, nrm.data(), nrm.size() * 4) &&
             up(s->nodes4, s->bvh.nodes4.data(), s->bvh.nodes4.size() * sizeof(Node4)) &&
             up(s->nodes2, s->bvh.nodes2.data(), s->bvh.nodes2.size() * sizeof(Node2)) &&
-            up(s->nodes4f, s->bvh.nodes4f.empty() ? (const void *) tri.data() : (const void *) s->bvh.nodes4f.data(),
-               s->bvh.nodes4f.empty() ? 16 : s->bvh.nodes4f.size() * sizeof(Node4)) &&
             up(s->trisf, trif.data(), trif.size() * 4) &&
             up(s->nodes8q, s->bvh.nodes8q.empty() ? (const void *) tri.data() : (const void *) s->bvh.nodes8q.data(),
                s->bvh.nodes8q.empty() ? 16 : s->bvh.nodes8q.size() * 4) &&
@@ -311,7 +303,7 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
             up(s->lights, lights ? (const void *) lights : (const void *) mats, n_lights ? (size_t) n_lights * sizeof(mirt_light) : 4);
   if (ok) {
     s->trace_threads = (uint32_t) (G.n_cu * G.blocks_per_cu * TRACE_BLOCK);
-    int need = std::max(3 * ((int) std::max(s->bvh.depth4, s->bvh.depth4f) + 2), 7 * ((int) s->bvh.depth8 + 2)) - LDS_STACK + 1;
+    int need = std::max(3 * ((int) s->bvh.depth4 + 2), 7 * ((int) s->bvh.depth8 + 2)) - LDS_STACK + 1;
     s->ovf_depth = (uint32_t) (need > 1 ? need : 1);
     ok = s->ovf.ensure((size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
   }
@@ -445,14 +437,13 @@ TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal) {
   TraceArgs t;
   memset(&t, 0, sizeof t);
   uint32_t *ctrl = s->ctrl.as<uint32_t>();
-  t.nodes4 = traversal == 0 ? s->nodes4f.as<float4>() : s->nodes4.as<float4>();
+  t.nodes4 = s->nodes4.as<float4>();
   t.nodes2 = s->nodes2.as<float4>();
   t.tris = traversal == 0 ? s->trisf.as<float4>() : s->tris.as<float4>();
   t.tris2 = s->tris.as<float4>();
   t.require_unit = traversal == 0 ? 1 : 0;
-  t.min_lanes = G.min_lanes;
   t.nodes8 = s->nodes8q.p;
-  t.width = G.fast_width;
+  t.spheres = s->has_spheres ? 1 : 0;
   t.refill_min = G.refill_min;
   t.static_16th = G.static_16th;
   t.big = s->big.as<uint2>();
@@ -478,14 +469,13 @@ TraceArgs shadow_args(mirt_scene *s, uint32_t traversal) {
   TraceArgs t;
   memset(&t, 0, sizeof t);
   uint32_t *ctrl = s->ctrl.as<uint32_t>();
-  t.nodes4 = traversal == 0 ? s->nodes4f.as<float4>() : s->nodes4.as<float4>();
+  t.nodes4 = s->nodes4.as<float4>();
   t.nodes2 = s->nodes2.as<float4>();
   t.tris = traversal == 0 ? s->trisf.as<float4>() : s->tris.as<float4>();
   t.tris2 = s->tris.as<float4>();
   t.require_unit = traversal == 0 ? 1 : 0;
-  t.min_lanes = G.min_lanes;
   t.nodes8 = s->nodes8q.p;
-  t.width = G.fast_width;
+  t.spheres = s->has_spheres ? 1 : 0;
   t.refill_min = G.refill_min;
   t.static_16th = G.static_16th;
   t.big = s->big.as<uint2>();
@@ -887,8 +877,8 @@ int mirt_bvh_build_host_prims(const float *prim_pos, const uint8_t *prim_type, u
   counts[3] = b.depth4;
   counts[4] = (uint32_t) (b.nodes8q.size() / (sizeof(Node8Q) / 4));
   counts[5] = b.depth8;
-  counts[6] = (uint32_t) b.nodes4f.size();
-  counts[7] = b.depth4f;
+  counts[6] = 0;
+  counts[7] = 0;
   if (nodes2_out) memcpy(nodes2_out, b.nodes2.data(), b.nodes2.size() * sizeof(Node2));
   if (flat_to_orig) memcpy(flat_to_orig, b.flat_to_orig.data(), b.flat_to_orig.size() * 4);
   if (nodes4_out) memcpy(nodes4_out, b.nodes4.data(), b.nodes4.size() * sizeof(Node4));

@@ -525,11 +525,6 @@ void build_fast_tree(const float *tri_pos_flat, const uint8_t *prim_type_flat, u
   }
   sb.prepare(n);
   sb.build(0, n);
-  bvh.nodes4f.clear();
-  std::vector<uint32_t> big_unused;
-  Collapser c(CollapseIO{n2, bvh.nodes4f, big_unused});
-  c.build(0, 0);
-  bvh.depth4f = c.max_depth;
   Collapser8 c8(n2);
   c8.build(0, 0);
   bvh.depth8 = c8.max_depth;

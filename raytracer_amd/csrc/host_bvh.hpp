@@ -43,11 +43,8 @@ struct HostBVH {
   std::vector<Node4> nodes4;
   std::vector<uint32_t> big;                 // (start, count) pairs of reference leaves with more than LEAF_MAX primitives
   uint32_t depth4 = 0;
-  // the ordered traversal's own tree (binned SAH) and its triangle order
-  std::vector<Node4> nodes4f;
-  std::vector<uint32_t> fast_to_flat;        // fast-order slot -> flat (reference-order) index
-  uint32_t depth4f = 0;
-  // the same SAH tree folded to 8-wide nodes with 8-bit quantised child boxes (96 bytes, Node8Q), what the kernel walks
+  // the ordered traversal's own tree: binned SAH folded to 8-wide nodes with 8-bit quantised child boxes (96 bytes, Node8Q)
+  std::vector<uint32_t> fast_to_flat;        // that tree's primitive order -> flat (reference-order) index
   std::vector<uint32_t> nodes8q;             // 24 words per node
   uint32_t depth8 = 0;
 };

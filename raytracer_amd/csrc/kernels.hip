@@ -3,7 +3,9 @@
 //   k_init            per-slot path state, reference seed procedure (renderer.cuh:50-51)
 //   k_logic           fold shadow results -> finish sample -> shade the hit (raytracer.cuh:30-126) -> emit the next
 //                     extension ray and the shadow rays into compacted queues (wave64 ballot / mbcnt)
-//   k_trace4<ANY,..>  persistent-thread traversal of the 4-wide BVH (LDS stack, dynamic ray fetch)
+//   k_trace_fast<..>  traversal 0: persistent-thread ordered traversal of the 8-wide quantised SAH tree (LDS stack)
+//   k_redo<ANY>       the reference walk, one wave per ray, for the rays k_trace_fast sets aside
+//   k_trace4<ANY,..>  traversal 1: the reference tree folded to 4-wide nodes, reference visiting order (exact)
 //   k_trace2<ANY>     the reference's own BVH2 walk (bvh.cuh:49-107), used for the `traversal = 2` cross-check and
 //                     for the few rays whose slab / hit arithmetic goes non-finite (results then depend on visit order)
 //   k_tonemap         film: divide + threshold-table tonemap (util/image.cuh:36-48)
@@ -467,11 +469,12 @@ __device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const
 // inside its edges, a sphere at either root) at a distance within NEAR (relative) of one of the two limits the accept test
 // compares against.  For such a hit the reference's own outcome hangs on whether ITS leaf box passed `tmin <= tmax`
 // (bbox.cuh:77) in the last ulps, which no other tree can know: the caller hands the ray to the reference walk (k_redo).
+template<bool SPH>
 __device__ __forceinline__ bool tri_test_near(const float4 *tris, uint32_t idx, const LaneRay &r, float max_t, float near_rel,
                                               float &t, float &by, float &bz, uint32_t &flat, bool &near) {
   const float4 q0 = tris[3 * (size_t) idx], q1 = tris[3 * (size_t) idx + 1], q2 = tris[3 * (size_t) idx + 2];
   flat = f2u(q2.y);
-  if (f2u(q2.z) != 0u) {
+  if (SPH && f2u(q2.z) != 0u) {
     const SphereHit h = sphere_eval(q0, q1, r);
     t = h.t; by = 0.f; bz = 0.f;
     const float b0 = near_rel * fabsf(h.t0), b1 = near_rel * fabsf(h.t1);
@@ -628,16 +631,10 @@ __global__ void __launch_bounds__(256) k_redo(TraceArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------- k_trace4 (wide BVH)
-// MODE 0: its own (SAH) tree, children sorted near-to-far.  The nearest hit does not depend on the tree or the order unless
-//         two candidates (or a candidate and the ray's t limits) lie within NEAR of each other; those rays are re-traced
-//         by the reference walk, so the result equals the reference's.  MODE 1: the reference's tree in its DFS order.
-template<bool ANY, int MODE, bool COUNT>
+// traversal 1: the reference's BVH2 folded to 4-wide nodes, children visited in the reference's DFS order, exact slab
+// arithmetic.  Provably the reference's result for finite arithmetic; the parity mode.
+template<bool ANY, bool COUNT>
 __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
-  // MODE 0 only.  NEAR: relative width of the "too close to call" band around the accept limits (see tri_test_near);
-  // SLACK: box culling keeps everything up to (1 + NEAR) * limit plus the slab arithmetic's own rounding.
-  constexpr float NEAR = 1.0e-5f;
-  constexpr float SLACK = 1.0f + 2.5e-5f;
-
   extern __shared__ uint2 lds_stack[];                    // [LDS_STACK][TRACE_BLOCK]
   const uint32_t tid = threadIdx.x;
   const uint32_t gtid = blockIdx.x * TRACE_BLOCK + tid;
@@ -670,7 +667,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
     while (sp > 0) {
       sp--;
       uint2 e = (sp < LDS_STACK) ? lds_stack[sp * TRACE_BLOCK + tid] : a.ovf[(size_t) (sp - LDS_STACK) * nthreads + gtid];
-      if (ANY || u2f(e.y) <= (MODE == 0 ? r.best_t * SLACK : r.best_t)) { cur = e.x; break; }
+      if (ANY || u2f(e.y) <= r.best_t) { cur = e.x; break; }
     }
   };
 
@@ -758,26 +755,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
         const float t1z = (loz[c] - r.o.z) * r.inv.z, t2z = (hiz[c] - r.o.z) * r.inv.z;
         const float tmn = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fmaxf(fminf(t1z, t2z), 0.0f));
         const float tmx = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fminf(fmaxf(t1z, t2z), r.best_t));
-        // MODE 1 keeps the reference's exact comparison (same boxes as the reference: same decisions).  The ordered
-        // traversal walks its own, tighter boxes, where a slab distance and a Moeller-Trumbore distance of the same point
-        // can disagree in the last ulp (coplanar or box-flush triangles): a few ulps of slack keep every box whose
-        // triangles could still pass the reference's accept test; the accept test itself stays exact.
-        const bool hit = (ch[c] != CHILD_EMPTY) &&
-                         (MODE == 0 ? (tmn <= tmx * SLACK && tmx * SLACK > r.min_t) : (tmn <= tmx && tmx > r.min_t));
+        // the reference's exact comparison (same boxes as the reference: same decisions)
+        const bool hit = (ch[c] != CHILD_EMPTY) && (tmn <= tmx && tmx > r.min_t);
         key[c] = hit ? tmn : MIRT_INF;
         if (!hit) ch[c] = CHILD_EMPTY;
-      }
-      if (MODE == 0 && !ANY) {
-        // 5-comparator sorting network on (key, child): nearest first
-#define MIRT_CE(i, j)                                                         \
-  {                                                                           \
-    const bool sw = key[j] < key[i];                                          \
-    const float ki = sw ? key[j] : key[i], kj = sw ? key[i] : key[j];         \
-    const uint32_t ci = sw ? ch[j] : ch[i], cj = sw ? ch[i] : ch[j];          \
-    key[i] = ki; key[j] = kj; ch[i] = ci; ch[j] = cj;                         \
-  }
-        MIRT_CE(0, 1) MIRT_CE(2, 3) MIRT_CE(0, 2) MIRT_CE(1, 3) MIRT_CE(1, 2)
-#undef MIRT_CE
       }
       // descend into the first surviving child, push the others so that the earlier ones pop first
       uint32_t first = CHILD_EMPTY;
@@ -812,11 +793,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
           if (lane_rank(__ballot(1)) == 0) n_tri_steps++;
         }
         uint32_t flat;
-        bool acc, near = false;
-        if (MODE == 0) acc = tri_test_near(a.tris, i, r, r.best_t, NEAR, t, by, bz, flat, near);
-        else acc = tri_test(a.tris, i, r, r.best_t, t, by, bz, flat);
-        if (MODE == 0 && near) { irregular = true; break; }               // two candidates (or a candidate and a limit) too close to call
-        if (acc) {
+        if (tri_test(a.tris, i, r, r.best_t, t, by, bz, flat)) {
           if (!(fabsf(t) < MIRT_INF)) { irregular = true; break; }        // accepted NaN / inf hit
           r.best_t = t; r.b1 = by; r.b2 = bz; r.best_idx = (int32_t) flat;
           if (ANY) { found = true; break; }
@@ -868,20 +845,15 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
 // nearest hit of a ray does not depend on the tree, the boxes or the visiting order unless two candidates (or a candidate
 // and one of the ray's t limits) lie within NEAR of each other, and those rays are handed to the reference walk (k_redo).
 // So the box test only has to be conservative, which buys:
-//   * slabs as one fma per plane, t = plane * inv - o * inv, with the near / far plane picked by the direction's sign
-//     through the load address (no min/max per axis); the rounding of o * inv is covered by widening each axis by
-//     AXIS_EPS * |o * inv| and the comparison by SLACK;
+//   * 96-byte nodes with 8 children whose boxes are 8-bit planes on a power-of-two grid anchored at the node's minimum
+//     corner p:  t = (p + q * 2^e - o) * inv = q * (2^e * inv) + (p - o) * inv, one cvt + one fma per plane, the near /
+//     far plane picked by the direction's sign; the rounding of (p - o) * inv is covered by widening each axis by
+//     AXIS_EPS * |(p - o) * inv| and the comparison by SLACK;
 //   * one loop in which every lane advances by one node OR one triangle per trip ("if-if"): the while-while form left
-//     75 % of the lanes idle in the node loop on this tree (tools/count_frame.py).  A part runs only when at least
-//     MIN_LANES lanes want it or it is the majority, so stragglers wait for company instead of issuing for themselves.
-// The triangle test itself is the exact one (tri_test_near).
-constexpr int FAST_MIN_LANES = 16;
-
-#ifndef MIRT_FAST_ATTR
-#define MIRT_FAST_ATTR
-#endif
-template<bool ANY, bool COUNT, int WIDTH>
-__global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(TraceArgs a) {
+//     75 % of the lanes idle in the node loop on this tree (tools/count_frame.py).
+// The primitive test itself is the exact one (tri_test_near).  SPH: the scene has sphere primitives.
+template<bool ANY, bool COUNT, bool SPH>
+__global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
   constexpr float NEAR = 1.0e-5f;
   constexpr float SLACK = 1.0f + 2.5e-5f;
   constexpr float AXIS_EPS = 4.76837158e-7f;              // 2^-21
@@ -897,8 +869,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(Trace
   LaneRay r;
   r.id = 0; r.best_idx = -1; r.best_t = 0; r.min_t = 0; r.b1 = r.b2 = 0;
   r.o = r.d = r.inv = mk(0, 0, 0);
-  V3 c_near = mk(0, 0, 0), c_far = mk(0, 0, 0);           // -(o * inv) widened down / up
-  uint32_t off_x = 0, off_y = 0, off_z = 0;               // 0: the near plane is the box minimum, 48: the maximum
   bool active = false;
   uint32_t cur = CHILD_EMPTY, tri_i = 0, tri_n = 0;
   // Work distribution.  Device-scope atomics on one address retire at ~11 ns each no matter who issues them, so a scheme
@@ -948,9 +918,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(Trace
   };
 
   while (true) {
-    // ---------------------------------------------------------------- dynamic fetch (see k_trace4)
+    // ---------------------------------------------------------------- fetch
     // (refilling costs ~150 instructions for the whole wave - normalise, three correctly rounded reciprocals - so it waits
-    // until enough lanes are idle to be worth it)
+    // until a few lanes are idle)
     const uint64_t need = __ballot(!active);
     if (need != 0 && !wave_done && ((uint32_t) __popcll(need) >= a.refill_min || need == ~0ull)) {
       if (w_next >= w_end) {
@@ -994,20 +964,15 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(Trace
             load_ray(a, id, r);
             // Rays the shortcut arithmetic is not meant for take the reference walk: non-finite origin / direction /
             // reciprocal (the reference's result then depends on its visiting order), a direction almost parallel to an
-            // axis plane (o * inv would lose all precision), and ctor directions that are not unit length (the reference
-            // prunes boxes along the un-normalised direction but measures hits along the normalised one, ray.cuh:19-21).
+            // axis plane ((p - o) * inv would lose all precision), and ctor directions that are not unit length (the
+            // reference prunes boxes along the un-normalised direction but measures hits along the normalised one,
+            // ray.cuh:19-21; the integrator only makes unit directions).
             const float4 rd = a.ray_d[id];
             const float l2 = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
             const bool regular = finite3(r.o) && finite3(r.d) && (r.best_t == r.best_t) && (r.min_t == r.min_t) &&
                                  fabsf(r.inv.x) < INV_LIMIT && fabsf(r.inv.y) < INV_LIMIT && fabsf(r.inv.z) < INV_LIMIT &&
                                  (fabsf(l2 - 1.0f) < 1e-4f);
             if (regular) {
-              const V3 oi = mk(r.o.x * r.inv.x, r.o.y * r.inv.y, r.o.z * r.inv.z);
-              c_near = mk(-oi.x - AXIS_EPS * fabsf(oi.x), -oi.y - AXIS_EPS * fabsf(oi.y), -oi.z - AXIS_EPS * fabsf(oi.z));
-              c_far = mk(-oi.x + AXIS_EPS * fabsf(oi.x), -oi.y + AXIS_EPS * fabsf(oi.y), -oi.z + AXIS_EPS * fabsf(oi.z));
-              off_x = r.inv.x < 0 ? 48u : 0u;
-              off_y = r.inv.y < 0 ? 48u : 0u;
-              off_z = r.inv.z < 0 ? 48u : 0u;
               active = true;
               sp = 0;
               enter(0);
@@ -1027,108 +992,54 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(Trace
     }
 
     // ---------------------------------------------------------------- one step per lane: a node ...
-    const bool at_node = active && !(cur & CHILD_LEAF);
-    const int cn = __popcll(__ballot(at_node)), cl = __popcll(__ballot(active && !at_node));
-    const bool run_nodes = cn > 0 && (cn >= (int) a.min_lanes || cn >= cl);
-    if (run_nodes && at_node) {
+    if (active && !(cur & CHILD_LEAF)) {
       if (COUNT) {
         n_nodes++;
         if (lane_rank(__ballot(1)) == 0) n_node_steps++;
       }
-      if constexpr (WIDTH == 8) {
-        // 96-byte node: 8 children, 8-bit planes on a power-of-two grid anchored at the node's minimum corner p.
-        //   t = (p + q * 2^e - o) * inv = q * (2^e * inv) + (p - o) * inv : one cvt + one fma per plane
-        const uint4 *nq = (const uint4 *) ((const char *) a.nodes8 + (size_t) cur * 96u);
-        const uint4 H = nq[0], C0 = nq[1], C1 = nq[2], Q0 = nq[3], Q1 = nq[4], Q2 = nq[5];
-        const float sx = u2f((H.w & 0xFFu) << 23) * r.inv.x, sy = u2f(((H.w >> 8) & 0xFFu) << 23) * r.inv.y,
-                    sz = u2f(((H.w >> 16) & 0xFFu) << 23) * r.inv.z;
-        const float bx = (u2f(H.x) - r.o.x) * r.inv.x, by_ = (u2f(H.y) - r.o.y) * r.inv.y, bz_ = (u2f(H.z) - r.o.z) * r.inv.z;
-        const float ex = AXIS_EPS * fabsf(bx), ey = AXIS_EPS * fabsf(by_), ez = AXIS_EPS * fabsf(bz_);
-        const float cnx = bx - ex, cny = by_ - ey, cnz = bz_ - ez, cfx = bx + ex, cfy = by_ + ey, cfz = bz_ + ez;
-        const bool ngx = r.inv.x < 0, ngy = r.inv.y < 0, ngz = r.inv.z < 0;
-        // Q0 = qlo_x[8] qlo_y[8], Q1 = qlo_z[8] qhi_x[8], Q2 = qhi_y[8] qhi_z[8]; near plane = lo unless the ray runs backwards
-        const uint32_t nxw[2] = {ngx ? Q1.z : Q0.x, ngx ? Q1.w : Q0.y}, fxw[2] = {ngx ? Q0.x : Q1.z, ngx ? Q0.y : Q1.w};
-        const uint32_t nyw[2] = {ngy ? Q2.x : Q0.z, ngy ? Q2.y : Q0.w}, fyw[2] = {ngy ? Q0.z : Q2.x, ngy ? Q0.w : Q2.y};
-        const uint32_t nzw[2] = {ngz ? Q2.z : Q1.x, ngz ? Q2.w : Q1.y}, fzw[2] = {ngz ? Q1.x : Q2.z, ngz ? Q1.y : Q2.w};
-        const uint32_t ch[8] = {C0.x, C0.y, C0.z, C0.w, C1.x, C1.y, C1.z, C1.w};
-        const float far_limit = r.best_t;
-        uint32_t first = CHILD_EMPTY;
-        float first_key = MIRT_INF;
+      const uint4 *nq = (const uint4 *) ((const char *) a.nodes8 + (size_t) cur * 96u);
+      const uint4 H = nq[0], C0 = nq[1], C1 = nq[2], Q0 = nq[3], Q1 = nq[4], Q2 = nq[5];
+      const float sx = u2f((H.w & 0xFFu) << 23) * r.inv.x, sy = u2f(((H.w >> 8) & 0xFFu) << 23) * r.inv.y,
+                  sz = u2f(((H.w >> 16) & 0xFFu) << 23) * r.inv.z;
+      const float bx = (u2f(H.x) - r.o.x) * r.inv.x, by_ = (u2f(H.y) - r.o.y) * r.inv.y, bz_ = (u2f(H.z) - r.o.z) * r.inv.z;
+      const float ex = AXIS_EPS * fabsf(bx), ey = AXIS_EPS * fabsf(by_), ez = AXIS_EPS * fabsf(bz_);
+      const float cnx = bx - ex, cny = by_ - ey, cnz = bz_ - ez, cfx = bx + ex, cfy = by_ + ey, cfz = bz_ + ez;
+      const bool ngx = r.inv.x < 0, ngy = r.inv.y < 0, ngz = r.inv.z < 0;
+      // Q0 = qlo_x[8] qlo_y[8], Q1 = qlo_z[8] qhi_x[8], Q2 = qhi_y[8] qhi_z[8]; near plane = lo unless the ray runs backwards
+      const uint32_t nxw[2] = {ngx ? Q1.z : Q0.x, ngx ? Q1.w : Q0.y}, fxw[2] = {ngx ? Q0.x : Q1.z, ngx ? Q0.y : Q1.w};
+      const uint32_t nyw[2] = {ngy ? Q2.x : Q0.z, ngy ? Q2.y : Q0.w}, fyw[2] = {ngy ? Q0.z : Q2.x, ngy ? Q0.w : Q2.y};
+      const uint32_t nzw[2] = {ngz ? Q2.z : Q1.x, ngz ? Q2.w : Q1.y}, fzw[2] = {ngz ? Q1.x : Q2.z, ngz ? Q1.y : Q2.w};
+      const uint32_t ch[8] = {C0.x, C0.y, C0.z, C0.w, C1.x, C1.y, C1.z, C1.w};
+      const float far_limit = r.best_t;
+      uint32_t first = CHILD_EMPTY;
+      float first_key = MIRT_INF;
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-          const int w = c >> 2, sh = 8 * (c & 3);
-          const float qnx = (float) ((nxw[w] >> sh) & 0xFFu), qny = (float) ((nyw[w] >> sh) & 0xFFu), qnz = (float) ((nzw[w] >> sh) & 0xFFu);
-          const float qfx = (float) ((fxw[w] >> sh) & 0xFFu), qfy = (float) ((fyw[w] >> sh) & 0xFFu), qfz = (float) ((fzw[w] >> sh) & 0xFFu);
-          const float tnx = fmaf(qnx, sx, cnx), tny = fmaf(qny, sy, cny), tnz = fmaf(qnz, sz, cnz);
-          const float tfx = fmaf(qfx, sx, cfx), tfy = fmaf(qfy, sy, cfy), tfz = fmaf(qfz, sz, cfz);
-          const float tmn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-          const float tmx = fminf(fminf(tfx, tfy), fminf(tfz, far_limit)) * SLACK;
-          const bool hit = (ch[c] != CHILD_EMPTY) && (tmn <= tmx) && (tmx > r.min_t);
-          if (hit) {
-            // the nearest child is entered next, the others wait on the stack with their entry distance
-            if (ANY ? (first == CHILD_EMPTY) : (tmn < first_key || first == CHILD_EMPTY)) {
-              if (first != CHILD_EMPTY) push(first, first_key);
-              first = ch[c];
-              first_key = tmn;
-            } else {
-              push(ch[c], tmn);
-            }
+      for (int c = 0; c < 8; c++) {
+        const int w = c >> 2, sh = 8 * (c & 3);
+        const float qnx = (float) ((nxw[w] >> sh) & 0xFFu), qny = (float) ((nyw[w] >> sh) & 0xFFu), qnz = (float) ((nzw[w] >> sh) & 0xFFu);
+        const float qfx = (float) ((fxw[w] >> sh) & 0xFFu), qfy = (float) ((fyw[w] >> sh) & 0xFFu), qfz = (float) ((fzw[w] >> sh) & 0xFFu);
+        const float tnx = fmaf(qnx, sx, cnx), tny = fmaf(qny, sy, cny), tnz = fmaf(qnz, sz, cnz);
+        const float tfx = fmaf(qfx, sx, cfx), tfy = fmaf(qfy, sy, cfy), tfz = fmaf(qfz, sz, cfz);
+        const float tmn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tmx = fminf(fminf(tfx, tfy), fminf(tfz, far_limit)) * SLACK;
+        const bool hit = (ch[c] != CHILD_EMPTY) && (tmn <= tmx) && (tmx > r.min_t);
+        if (hit) {
+          // the nearest child is entered next, the others wait on the stack with their entry distance
+          if (ANY ? (first == CHILD_EMPTY) : (tmn < first_key || first == CHILD_EMPTY)) {
+            if (first != CHILD_EMPTY) push(first, first_key);
+            first = ch[c];
+            first_key = tmn;
+          } else {
+            push(ch[c], tmn);
           }
         }
-        if (first != CHILD_EMPTY) enter(first);
-        else pop();
-      } else {
-        const char *nb = (const char *) a.nodes4 + (size_t) cur * 128u;
-        const float4 NX = *(const float4 *) (nb + off_x), FX = *(const float4 *) (nb + (48u - off_x));
-        const float4 NY = *(const float4 *) (nb + 16u + off_y), FY = *(const float4 *) (nb + (64u - off_y));
-        const float4 NZ = *(const float4 *) (nb + 32u + off_z), FZ = *(const float4 *) (nb + (80u - off_z));
-        const float4 CHf = *(const float4 *) (nb + 96u);
-        const float nx[4] = {NX.x, NX.y, NX.z, NX.w}, ny[4] = {NY.x, NY.y, NY.z, NY.w}, nz[4] = {NZ.x, NZ.y, NZ.z, NZ.w};
-        const float fx[4] = {FX.x, FX.y, FX.z, FX.w}, fy[4] = {FY.x, FY.y, FY.z, FY.w}, fz[4] = {FZ.x, FZ.y, FZ.z, FZ.w};
-        uint32_t ch[4] = {f2u(CHf.x), f2u(CHf.y), f2u(CHf.z), f2u(CHf.w)};
-        float key[4];
-        const float far_limit = r.best_t;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const float tnx = fmaf(nx[c], r.inv.x, c_near.x), tny = fmaf(ny[c], r.inv.y, c_near.y), tnz = fmaf(nz[c], r.inv.z, c_near.z);
-          const float tfx = fmaf(fx[c], r.inv.x, c_far.x), tfy = fmaf(fy[c], r.inv.y, c_far.y), tfz = fmaf(fz[c], r.inv.z, c_far.z);
-          const float tmn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-          const float tmx = fminf(fminf(tfx, tfy), fminf(tfz, far_limit)) * SLACK;
-          const bool hit = (ch[c] != CHILD_EMPTY) && (tmn <= tmx) && (tmx > r.min_t);
-          key[c] = hit ? tmn : MIRT_INF;
-          if (!hit) ch[c] = CHILD_EMPTY;
-        }
-        if (!ANY) {
-#define MIRT_CE(i, j)                                                         \
-  {                                                                           \
-    const bool sw = key[j] < key[i];                                          \
-    const float ki = sw ? key[j] : key[i], kj = sw ? key[i] : key[j];         \
-    const uint32_t ci = sw ? ch[j] : ch[i], cj = sw ? ch[i] : ch[j];          \
-    key[i] = ki; key[j] = kj; ch[i] = ci; ch[j] = cj;                         \
-  }
-          MIRT_CE(0, 1) MIRT_CE(2, 3) MIRT_CE(0, 2) MIRT_CE(1, 3) MIRT_CE(1, 2)
-#undef MIRT_CE
-        }
-        uint32_t first = CHILD_EMPTY;
-#pragma unroll
-        for (int c = 3; c >= 0; c--) {
-          if (ch[c] != CHILD_EMPTY) {
-            bool earlier = false;
-#pragma unroll
-            for (int e = 0; e < c; e++) earlier = earlier || (ch[e] != CHILD_EMPTY);
-            if (earlier) push(ch[c], key[c]);
-            else first = ch[c];
-          }
-        }
-        if (first != CHILD_EMPTY) enter(first);
-        else pop();
       }
+      if (first != CHILD_EMPTY) enter(first);
+      else pop();
     }
 
-    // ---------------------------------------------------------------- ... or a triangle (lanes that just reached a leaf join in)
-    const bool at_leaf = active && cur != CHILD_EMPTY && (cur & CHILD_LEAF);
-    const int cl2 = __popcll(__ballot(at_leaf));
-    if (cl2 > 0 && (cl2 >= (int) a.min_lanes || !run_nodes) && at_leaf) {
+    // ---------------------------------------------------------------- ... or a primitive (lanes that just reached a leaf join in)
+    if (active && cur != CHILD_EMPTY && (cur & CHILD_LEAF)) {
       float t, by, bz;
       uint32_t flat;
       bool near = false;
@@ -1136,7 +1047,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_FAST_ATTR k_trace_fast(Trace
         n_tris++;
         if (lane_rank(__ballot(1)) == 0) n_tri_steps++;
       }
-      const bool acc = tri_test_near(a.tris, tri_i, r, r.best_t, NEAR, t, by, bz, flat, near);
+      const bool acc = tri_test_near<SPH>(a.tris, tri_i, r, r.best_t, NEAR, t, by, bz, flat, near);
       tri_i++;
       tri_n--;
       if (near || (acc && !(fabsf(t) < MIRT_INF))) {
@@ -1296,7 +1207,7 @@ size_t trace4_lds_bytes() { return (size_t) LDS_STACK * TRACE_BLOCK * sizeof(uin
 
 int trace4_blocks_per_cu() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_fast<false, false, 8>, TRACE_BLOCK, trace4_lds_bytes()) != hipSuccess || nb < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace_fast<false, false, false>, TRACE_BLOCK, trace4_lds_bytes()) != hipSuccess || nb < 1)
     nb = 2;
   return nb;
 }
@@ -1311,28 +1222,22 @@ hipError_t launch_trace(const TraceArgs &a, bool any, uint32_t traversal, uint32
     else k_trace2<false><<<grid_blocks, 256, 0, st>>>(a);
   } else {
     const size_t lds = trace4_lds_bytes();
-    if (any && traversal == 0) {
-      if (a.width == 8) {
-        if (a.count) k_trace_fast<true, true, 8><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-        else k_trace_fast<true, false, 8><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+    if (traversal == 0) {
+#define MIRT_FAST(ANYV, CNTV, SPHV) k_trace_fast<ANYV, CNTV, SPHV><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a)
+      if (any) {
+        if (a.spheres) { if (a.count) MIRT_FAST(true, true, true); else MIRT_FAST(true, false, true); }
+        else { if (a.count) MIRT_FAST(true, true, false); else MIRT_FAST(true, false, false); }
       } else {
-        if (a.count) k_trace_fast<true, true, 4><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-        else k_trace_fast<true, false, 4><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+        if (a.spheres) { if (a.count) MIRT_FAST(false, true, true); else MIRT_FAST(false, false, true); }
+        else { if (a.count) MIRT_FAST(false, true, false); else MIRT_FAST(false, false, false); }
       }
+#undef MIRT_FAST
     } else if (any) {
-      if (a.count) k_trace4<true, 1, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-      else k_trace4<true, 1, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-    } else if (traversal == 0) {
-      if (a.width == 8) {
-        if (a.count) k_trace_fast<false, true, 8><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-        else k_trace_fast<false, false, 8><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-      } else {
-        if (a.count) k_trace_fast<false, true, 4><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-        else k_trace_fast<false, false, 4><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-      }
+      if (a.count) k_trace4<true, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      else k_trace4<true, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
     } else {
-      if (a.count) k_trace4<false, 1, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
-      else k_trace4<false, 1, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      if (a.count) k_trace4<false, true><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
+      else k_trace4<false, false><<<grid_blocks, TRACE_BLOCK, lds, st>>>(a);
     }
   }
   LAUNCH_CHECK();

@@ -49,11 +49,11 @@ struct RenderArgs {
 };
 
 struct TraceArgs {
-  const float4 *nodes4;                   // 8 float4 per wide node
-  const void *nodes8;                     // 96-byte quantised 8-wide nodes (k_trace_fast<.., 8>)
+  const float4 *nodes4;                   // traversal 1: 8 float4 per 4-wide node of the folded reference tree
+  const void *nodes8;                     // traversal 0: 96-byte quantised 8-wide nodes of the SAH tree (k_trace_fast)
   uint32_t refill_min;                    // k_trace_fast: idle lanes a wave collects before it fetches new rays
   uint32_t static_16th;                   // k_trace_fast: sixteenths of the queue handed out as per-workgroup slices
-  uint32_t width;                         // k_trace_fast: 8 (default) or 4
+  uint32_t spheres;                       // the scene has sphere primitives (selects the kernel instantiation)
   const float4 *nodes2;                   // 2 float4 per reference node
   const float4 *tris;                     // triangles in the order of the tree k_trace4 walks: p1, e1, e2, flat index
   const float4 *tris2;                    // triangles in the reference's flat order (k_trace2)
@@ -74,7 +74,6 @@ struct TraceArgs {
   unsigned long long *redo_stat;          // counts rays re-traced by the reference walk (may be null)
   unsigned long long *count_stat;         // [0] node visits, [1] triangle tests (counting launches only)
   uint32_t count;
-  uint32_t min_lanes;                     // k_trace_fast: lanes a loop part waits for before it runs (unless it is the majority)
   uint32_t require_unit;                  // traversal 0: rays whose ctor direction is not unit length go to k_trace2
 };
 
