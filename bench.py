@@ -50,6 +50,9 @@ def parse():
                     help="N > 1: spp slices (default: the wavefront loop runs spp/N times fewer, full-size iterations; 0.83-0.97 "
                          "per-rank efficiency measured with tools/part_probe.py) or interleaved 8x8 tiles (bit-identical to one "
                          "GPU, but every iteration shrinks to 1/N of the rays: 0.23 at N = 8)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="sample streams per pixel in flight (mirt_options.streams): same samples, fewer and larger wavefront "
+                         "iterations; 1 = one path per pixel at a time, the reference's order of summation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -121,7 +124,7 @@ def main():
     w, h = args.width, args.height
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
 
-    opt = dict(rng_mode=args.rng, traversal=args.traversal, profile=True)
+    opt = dict(rng_mode=args.rng, traversal=args.traversal, profile=True, streams=args.streams if args.rng == 1 else 0)
     if world > 1 and args.partition == "tile":
         opt.update(tile_rank=rank, tile_world=world)
     elif world > 1:
@@ -189,7 +192,7 @@ def main():
             "data": "synthetic (procedural stand-in scene: the reference's .obj meshes are absent)",
             "config": {"workload": f"{args.workload} {sd.n} tris, {w}x{h}, {args.spp} spp, depth {args.depth}, "
                                    f"2 lights, rng {'counter' if opt['rng_mode'] else 'xorshift'}, "
-                                   f"traversal {args.traversal}",
+                                   f"traversal {args.traversal}, {opt['streams']} sample streams",
                        "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
                        "scene_build_s": build_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

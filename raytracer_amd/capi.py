@@ -47,7 +47,8 @@ class Params(C.Structure):
 class Options(C.Structure):
     _fields_ = [("rng_mode", C.c_uint32), ("seed", C.c_uint32), ("traversal", C.c_uint32), ("tile_rank", C.c_uint32),
                 ("tile_world", C.c_uint32), ("sample_begin", C.c_uint32), ("sample_count", C.c_uint32),
-                ("glass_int_abs", C.c_uint32), ("reserved", C.c_uint32 * 8)]
+                ("glass_int_abs", C.c_uint32), ("flags", C.c_uint32), ("streams", C.c_uint32),
+                ("reserved", C.c_uint32 * 6)]
 
 
 class Stats(C.Structure):
@@ -207,12 +208,13 @@ class Scene:
 
     @staticmethod
     def options(rng_mode=0, seed=0, traversal=0, tile_rank=0, tile_world=1, sample_begin=0, sample_count=0,
-                glass_int_abs=0, profile=False, count=False):
+                glass_int_abs=0, profile=False, count=False, streams=0):
         o = Options()
         o.rng_mode, o.seed, o.traversal = rng_mode, seed, traversal
         o.tile_rank, o.tile_world = tile_rank, tile_world
         o.sample_begin, o.sample_count, o.glass_int_abs = sample_begin, sample_count, glass_int_abs
-        o.reserved[0] = (1 if profile else 0) | (2 if count else 0)
+        o.flags = (1 if profile else 0) | (2 if count else 0)
+        o.streams = streams
         return o
 
     def render(self, w, h, spp=4, spl=1, batch=64, tol=0.05, depth=4, leaf=4, **opt):

@@ -113,11 +113,11 @@ struct mirt_scene {
   uint32_t trace_threads = 0;
   // work buffers (sized per render)
   DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2], mf_queue;
-  DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t;
+  DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t, planes;
   size_t device_bytes() const {
     const DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                            &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0],
-                           &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue};
+                           &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue, &planes};
     size_t s = 0;
     for (auto *b: all) s += b->bytes;
     return s;
@@ -125,7 +125,7 @@ struct mirt_scene {
   void release_all() {
     DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                      &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0], &redo_q[1],
-                     &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue};
+                     &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue, &planes};
     for (auto *b: all) b->release();
   }
 };
@@ -537,21 +537,31 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   if (o.rng_mode > 1 || o.traversal > 2) return fail(MIRT_E_ARG, "bad rng_mode / traversal");
   if (o.traversal == 0 && !s->fast_ok) o.traversal = 1;
   if (o.tile_world > 1 && o.tile_rank >= o.tile_world) return fail(MIRT_E_ARG, "tile_rank >= tile_world");
-  const bool sliced = o.sample_count != 0 || o.sample_begin != 0;
-  if (sliced && o.rng_mode != 1) return fail(MIRT_E_ARG, "spp slices need rng_mode 1 (the xorshift stream is sequential per pixel)");
+  uint32_t streams = o.streams > 1 ? o.streams : 1;
+  const bool sliced = o.sample_count != 0 || o.sample_begin != 0 || streams > 1;
+  if (sliced && o.rng_mode != 1)
+    return fail(MIRT_E_ARG, "spp slices and sample streams need rng_mode 1 (the xorshift stream is sequential per pixel)");
+  if (streams > 16) return fail(MIRT_E_ARG, "at most 16 sample streams");
+  {
+    const uint32_t spp_here = o.sample_count ? o.sample_count : prm->samples_per_pixel;
+    if (streams > spp_here) streams = spp_here ? spp_here : 1;
+  }
   const uint64_t K64 = (uint64_t) s->n_lights * prm->samples_per_light;
   if (K64 > 0xFFFF) return fail(MIRT_E_LIMIT, "more than 65535 shadow rays per hit");
   const uint32_t K = (uint32_t) K64;
   const Partition part = make_partition(w, h, o);
-  if ((uint64_t) part.n_slots * (K ? K : 1) >= (1ull << 32)) return fail(MIRT_E_LIMIT, "shadow queue beyond 2^32 entries");
+  const uint64_t total_slots = (uint64_t) part.n_slots * streams;
+  if (total_slots * (K ? K : 1) >= (1ull << 32)) return fail(MIRT_E_LIMIT, "shadow queue beyond 2^32 entries");
   auto wall0 = std::chrono::steady_clock::now();
 
-  int rc = ensure_work(s, part.n_slots, K);
+  int rc = ensure_work(s, (uint32_t) total_slots, K);
   if (rc) return rc;
+  if (streams > 1) HIPCHK(s->planes.ensure((size_t) streams * w * h * 16));
 
   RenderArgs a;
   memset(&a, 0, sizeof a);
-  a.n_slots = part.n_slots; a.width = w; a.height = h;
+  a.n_slots = (uint32_t) total_slots; a.n_pixel_slots = part.n_slots; a.streams = streams;
+  a.width = w; a.height = h;
   a.tiles_x = part.tiles_x; a.tiles_y = part.tiles_y; a.tile_rank = part.rank; a.tile_world = part.world;
   a.rng_mode = o.rng_mode; a.seed = o.seed; a.sample_begin = o.sample_begin;
   a.spp = o.sample_count ? o.sample_count : prm->samples_per_pixel;
@@ -568,12 +578,12 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   uint32_t *ctrl = s->ctrl.as<uint32_t>();
   a.qcount = ctrl + CTRL_QCOUNT;
   a.ray_stats = s->ray_stats.as<unsigned long long>();
-  a.out_accum = (float4 *) accum_dev;
+  a.out_accum = streams > 1 ? s->planes.as<float4>() : (float4 *) accum_dev;
   a.tri_nrm = s->tri_nrm.as<float4>(); a.mats = s->mats.as<float4>(); a.lights = s->lights.as<float>();
   a.mf_queue = s->mf_queue.as<uint32_t>(); a.mf_count = ctrl + CTRL_MF;
 
-  const bool profile = stats && (o.reserved[0] & 1u);
-  const bool counting = stats && (o.reserved[0] & 2u);
+  const bool profile = stats && (o.flags & 1u);
+  const bool counting = stats && (o.flags & 2u);
   double ms_kind[3] = {0, 0, 0};
   uint32_t n_kind[3] = {0, 0, 0};
   std::vector<Timed> timed;
@@ -583,6 +593,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   HIPCHK(hipEventCreate(&evB));
 
   HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
+  if (streams > 1) HIPCHK(hipMemsetAsync(s->planes.p, 0, (size_t) streams * w * h * 16, G.stream));
   HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, 128, G.stream));
   HIPCHK(hipMemsetAsync(s->ctrl.p, 0, CTRL_WORDS * 4, G.stream));
   HIPCHK(hipEventRecord(evA, G.stream));
@@ -591,7 +602,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   if (part.n_slots) {
     HIPCHK(launch_init(a, G.stream));
     const uint64_t max_iters = (uint64_t) a.spp * ((uint64_t) a.max_depth + 3) + 8;
-    const TraceArgs tc = closest_args(s, part.n_slots, o.traversal), ts = shadow_args(s, o.traversal);
+    const TraceArgs tc = closest_args(s, a.n_slots, o.traversal), ts = shadow_args(s, o.traversal);
     bool done = false;
     for (uint64_t it = 0; !done; it++) {
       if (it >= max_iters + RING) {
@@ -646,6 +657,8 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
       }
     }
   }
+  if (streams > 1 && part.n_slots)
+    HIPCHK(launch_sum_planes(s->planes.as<float4>(), streams, w * h, (float4 *) accum_dev, G.stream));
   HIPCHK(hipEventRecord(evB, G.stream));
   HIPCHK(hipEventSynchronize(evB));
   uint32_t err = 0;

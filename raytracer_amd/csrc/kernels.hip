@@ -35,8 +35,10 @@ __device__ __forceinline__ uint32_t wave_reserve(uint32_t *counter, uint32_t n_e
 }
 
 __device__ __forceinline__ void slot_to_pixel(const RenderArgs &a, uint32_t slot, uint32_t &px, uint32_t &py, bool &valid) {
-  // slots are 8x8 pixel tiles (one wave = one tile); tiles are dealt round-robin over the processes of a tile partition
-  const uint32_t tile_local = slot >> 6, lane = slot & 63;
+  // slots are 8x8 pixel tiles (one wave = one tile); tiles are dealt round-robin over the processes of a tile partition;
+  // with sample streams the slot array repeats once per stream
+  const uint32_t pslot = a.streams > 1 ? slot % a.n_pixel_slots : slot;
+  const uint32_t tile_local = pslot >> 6, lane = pslot & 63;
   const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
   const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
   px = tx * 8 + (lane & 7);
@@ -68,8 +70,20 @@ __global__ void k_init(RenderArgs a) {
 }
 
 // ============================================================================================ k_logic
+// The share of a pixel's samples that slot `s` renders: all of them, or stream k's contiguous part.
+__device__ __forceinline__ void stream_share(const RenderArgs &a, uint32_t s, uint32_t &stream, uint32_t &first, uint32_t &count) {
+  stream = 0; first = 0; count = a.spp;
+  if (a.streams > 1) {
+    stream = s / a.n_pixel_slots;
+    const uint32_t per = a.spp / a.streams;
+    first = stream * per;
+    count = (stream == a.streams - 1) ? a.spp - per * (a.streams - 1) : per;
+  }
+}
+
 struct PathCtx {
   Rng rng;
+  uint32_t sample_base; // index of this slot's first sample in the pixel's sample sequence (counter mode)
   uint32_t i;          // 1-based index of the sample being accumulated (raytracer.cuh:97)
   uint32_t flags;
   uint32_t depth;
@@ -92,7 +106,7 @@ __device__ __forceinline__ void generate_camera_ray(const RenderArgs &a, uint32_
                                                     PathCtx &c, uint32_t sample_number, Emit &em) {
   if (c.rng.mode == 1) {
     c.rng.state = 0;
-    c.rng.sample = a.sample_begin + sample_number - 1;
+    c.rng.sample = c.sample_base + sample_number - 1;
   }
   float gx = rng_next(c.rng);
   float gy = rng_next(c.rng);
@@ -174,8 +188,11 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
   c.i = st.y;
   c.flags = flags0;
   c.depth = st.w;
+  uint32_t stream, share_first, share_count;
+  stream_share(a, s, stream, share_first, share_count);
+  c.sample_base = a.sample_begin + share_first;
   // counter mode: the path in flight belongs to sample i, or to i + 1 when it was started ahead of the finalisation
-  c.rng.sample = a.sample_begin + c.i + ((c.flags & F_AHEAD) ? 1u : 0u) - 1u;
+  c.rng.sample = c.sample_base + c.i + ((c.flags & F_AHEAD) ? 1u : 0u) - 1u;
 
   V3 total = mk(tot4.x, tot4.y, tot4.z);
   float s1 = tot4.w;
@@ -217,7 +234,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
       divisor = (float) ((int) c.i - 1);          // raytracer.cuh:124 after `break`: i was not incremented
     } else {
       c.i++;
-      if (c.i > a.spp) {
+      if (c.i > share_count) {
         finished = true;
         divisor = (float) ((int) c.i - 1);
       }
@@ -322,7 +339,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
           // the sample is complete except for its last shadow rays: finish it next iteration, and meanwhile already
           // start the following sample (its camera ray is traced alongside those shadow rays)
           c.flags |= F_PENDING;
-          if (c.i + 1 <= a.spp) {
+          if (c.i + 1 <= share_count) {
             c.flags |= F_AHEAD;
             a.mask[s] = make_float4(1, 1, 1, 0);
             generate_camera_ray(a, s, px, py, c, c.i + 1, em);
@@ -341,7 +358,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
   if (finished) {
     c.flags = F_DONE;
     n_shadow = 0;
-    a.out_accum[(size_t) py * a.width + px] = make_float4(acc4.x, acc4.y, acc4.z, divisor);
+    a.out_accum[(size_t) stream * a.width * a.height + (size_t) py * a.width + px] = make_float4(acc4.x, acc4.y, acc4.z, divisor);
   }
   a.total[s] = make_float4(total.x, total.y, total.z, s1);
   if (acc_dirty) a.accum[s] = acc4;
@@ -1111,6 +1128,7 @@ __global__ void k_probe_primary(RenderArgs a) {
   c.rng.key = (a.rng_mode == 1) ? ctr_key(py * a.width + px, a.seed) : 0;
   c.rng.sample = 0;
   c.i = 1; c.flags = 0; c.depth = 0;
+  c.sample_base = a.sample_begin;
   Emit em;
   em.ext = 0; em.nsh = 0;
   generate_camera_ray(a, s, px, py, c, 1, em);
@@ -1133,6 +1151,19 @@ __global__ void k_gather_primary(RenderArgs a, int32_t *idx_out, uint32_t *tbits
 __global__ void k_iota(uint32_t *q, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) q[i] = i;
+}
+
+// Sample streams: the per-stream partial sums (sum rgb, sample count) are added in stream order, so the result does not
+// depend on scheduling.
+__global__ void k_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n, float4 *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 acc = planes[i];
+  for (uint32_t k = 1; k < n_planes; k++) {
+    const float4 v = planes[(size_t) k * n + i];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  out[i] = acc;
 }
 
 // ============================================================================================ film
@@ -1194,6 +1225,11 @@ hipError_t launch_gather_primary(const RenderArgs &a, int32_t *idx, uint32_t *tb
 hipError_t launch_iota(uint32_t *q, uint32_t n, hipStream_t st) {
   if (n == 0) return hipSuccess;
   k_iota<<<(n + 255) / 256, 256, 0, st>>>(q, n);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n, float4 *out, hipStream_t st) {
+  k_sum_planes<<<(n + 255) / 256, 256, 0, st>>>(planes, n_planes, n, out);
   LAUNCH_CHECK();
   return hipSuccess;
 }

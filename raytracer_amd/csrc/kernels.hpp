@@ -27,6 +27,7 @@ constexpr int WORK_PARTS = 8;        // a trace launch splits its queue into thi
 struct RenderArgs {
   uint32_t n_slots, width, height, tiles_x, tiles_y, tile_rank, tile_world;
   uint32_t rng_mode, seed, sample_begin;
+  uint32_t n_pixel_slots, streams;        // streams > 1: slot = stream * n_pixel_slots + pixel slot (mirt_options.streams)
   uint32_t spp, spl, batch, max_depth, adaptive, glass_int_abs, n_lights;
   float tol;
   DCamera cam;
@@ -41,7 +42,7 @@ struct RenderArgs {
   uint32_t *sh_occ;
   uint32_t *ext_queue, *sh_queue, *qcount;
   unsigned long long *ray_stats;          // closest, shadow, paths
-  float4 *out_accum;                      // width * height, (sum rgb, divisor)
+  float4 *out_accum;                      // width * height, (sum rgb, divisor); streams > 1: `streams` such planes
   const float4 *tri_nrm;                  // 3 float4 per triangle: n1 n2 n3, material, original index
   const float4 *mats;                     // 3 float4 per material: mirt_bsdf (9 dwords) padded to 48 B
   uint32_t *mf_queue, *mf_count;          // slots whose hit material is MICROFACET: shaded by k_logic<true>
@@ -82,6 +83,7 @@ hipError_t launch_logic(const RenderArgs &a, bool deferred_microfacet, hipStream
 hipError_t launch_probe_primary(const RenderArgs &a, hipStream_t st);
 hipError_t launch_gather_primary(const RenderArgs &a, int32_t *idx, uint32_t *tb, hipStream_t st);
 hipError_t launch_iota(uint32_t *q, uint32_t n, hipStream_t st);
+hipError_t launch_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n, float4 *out, hipStream_t st);
 hipError_t launch_tonemap(const void *accum, uint32_t n, const float *table, int32_t *rgb, hipStream_t st);
 hipError_t launch_trace(const TraceArgs &a, bool any, uint32_t traversal, uint32_t grid_blocks, hipStream_t st);
 size_t trace4_lds_bytes();

@@ -273,6 +273,35 @@ def test_spp_slices_sum_to_the_full_frame(mirt):
     s.close()
 
 
+def test_sample_streams_render_the_same_samples(mirt):
+    """mirt_options.streams: S streams per pixel in flight, partial sums added in stream order.  Same samples as one
+    stream; the float sum is re-associated, so: ray counts equal, accumulators equal to 1e-5 relative, film >= 99.9 %."""
+    torch = pytest.importorskip("torch")
+    sc = scenes.cornell_scene(2, "mixed")
+    s = mirt.Scene(sc)
+    w, h, spp = 200, 120, 13                       # 13: streams get unequal shares
+    kw = dict(spp=spp, spl=1, batch=spp + 1, tol=0.0, depth=5, rng_mode=1, seed=7)
+    ref = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    st0 = dict(s.render_accum(w, h, ref.data_ptr(), **kw))
+    img0 = mirt.tonemap(ref.data_ptr(), w, h)
+    for streams in (2, 4, 16):
+        acc = torch.zeros_like(ref)
+        st = s.render_accum(w, h, acc.data_ptr(), streams=streams, **kw)
+        assert (st["closest_rays"], st["shadow_rays"], st["paths"]) == (st0["closest_rays"], st0["shadow_rays"], st0["paths"])
+        assert st["iterations"] < st0["iterations"]
+        a, b = acc.cpu().numpy(), ref.cpu().numpy()
+        assert (a[..., 3] == spp).all()
+        assert np.allclose(a[..., :3], b[..., :3], rtol=1e-5, atol=1e-6)
+        assert (mirt.tonemap(acc.data_ptr(), w, h) == img0).mean() >= 0.999
+        # deterministic: a second run gives the same bits
+        acc2 = torch.zeros_like(ref)
+        s.render_accum(w, h, acc2.data_ptr(), streams=streams, **kw)
+        assert torch.equal(acc, acc2)
+    with pytest.raises(mirt.MirtError):
+        s.render_accum(w, h, ref.data_ptr(), spp=4, rng_mode=0, streams=2)      # sequential RNG cannot be split
+    s.close()
+
+
 def test_device_tonemap_and_bmp(mirt, golden, tmp_path):
     import torch
 
