@@ -305,7 +305,8 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
     s->trace_threads = (uint32_t) (G.n_cu * G.blocks_per_cu * TRACE_BLOCK);
     int need = std::max(3 * ((int) s->bvh.depth4 + 2), 7 * ((int) s->bvh.depth8 + 2)) - LDS_STACK + 1;
     s->ovf_depth = (uint32_t) (need > 1 ? need : 1);
-    ok = s->ovf.ensure((size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
+    // two regions: the closest-hit and the shadow launch of an iteration run concurrently
+    ok = s->ovf.ensure(2 * (size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
   }
   if (!ok) {
     rc = fail(MIRT_E_DEVICE, std::string("scene upload failed: ") + hipGetErrorString(hipGetLastError()));
@@ -487,7 +488,7 @@ TraceArgs shadow_args(mirt_scene *s, uint32_t traversal) {
   t.qc_back = -1;
   t.occ = s->sh_occ.as<uint32_t>();
   t.work_head = ctrl + CTRL_WORK + WORK_PARTS * CTR_STRIDE;
-  t.ovf = s->ovf.as<uint2>();
+  t.ovf = s->ovf.as<uint2>() + (size_t) s->ovf_depth * s->trace_threads;
   t.ovf_depth = s->ovf_depth;
   t.redo_queue = s->redo_q[1].as<uint32_t>();
   t.redo_count = ctrl + CTRL_REDO + CTR_STRIDE;
