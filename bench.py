@@ -50,7 +50,7 @@ def parse():
                     help="N > 1: spp slices (default: the wavefront loop runs spp/N times fewer, full-size iterations; 0.83-0.97 "
                          "per-rank efficiency measured with tools/part_probe.py) or interleaved 8x8 tiles (bit-identical to one "
                          "GPU, but every iteration shrinks to 1/N of the rays: 0.23 at N = 8)")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=8,
                     help="sample streams per pixel in flight (mirt_options.streams): same samples, fewer and larger wavefront "
                          "iterations; 1 = one path per pixel at a time, the reference's order of summation")
     ap.add_argument("--no-cpu-baseline", action="store_true")

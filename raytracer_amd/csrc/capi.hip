@@ -65,14 +65,20 @@ struct Global {
   uint32_t refill_min = 8;
   bool serial = false;
   uint32_t static_16th = 12;
-  hipStream_t stream = nullptr;
-  hipStream_t side = nullptr;            // runs the closest-hit redo pass next to the shadow launch of the main stream
-  hipEvent_t fork_ev[RING] = {}, join_ev[RING] = {};
+  // Two pipes: a frame with sample streams is rendered as two independent wavefront loops over halves of the slots, each
+  // with its own pair of streams (main: k_logic + closest-hit traversal, side: shadow traversal), so that the HBM-bound
+  // k_logic of one half runs while the other half is in its traversals.  `stream` / `side` are pipe 0's.
+  hipStream_t stream = nullptr, side = nullptr;
+  hipStream_t pstream[2] = {}, pside[2] = {};
+  hipEvent_t fork_ev[2][RING] = {}, join_ev[2][RING] = {};
+  hipEvent_t pipe_ev[2] = {};
+  bool one_pipe = false;
+  bool blocks_forced = false;           // MIRT_BLOCKS_PER_CU given
   float table[256];
   bool table_exact = false;
   DevBuf d_table;
-  uint32_t *h_counts = nullptr;          // pinned: RING x QC_WORDS
-  hipEvent_t ring_ev[RING] = {};
+  uint32_t *h_counts = nullptr;          // pinned: 2 pipes x RING x QC_WORDS
+  hipEvent_t ring_ev[2][RING] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> pool;          // timing events for profiled renders (recorded without host syncs)
   size_t pool_used = 0;
@@ -146,25 +152,31 @@ int mirt_init(int device) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
   G.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  HIPCHK(hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking));
+  for (int p = 0; p < 2; p++) {
+    HIPCHK(hipStreamCreateWithFlags(&G.pstream[p], hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&G.pside[p], hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&G.pipe_ev[p], hipEventDisableTiming));
+    for (int i = 0; i < RING; i++) {
+      HIPCHK(hipEventCreateWithFlags(&G.ring_ev[p][i], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&G.fork_ev[p][i], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&G.join_ev[p][i], hipEventDisableTiming));
+    }
+  }
+  G.stream = G.pstream[0];
+  G.side = G.pside[0];
   G.table_exact = build_tonemap_table(G.table);
   HIPCHK(G.d_table.ensure(sizeof(G.table)));
   HIPCHK(hipMemcpy(G.d_table.p, G.table, sizeof(G.table), hipMemcpyHostToDevice));
-  HIPCHK(hipHostMalloc((void **) &G.h_counts, RING * QC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-  HIPCHK(hipStreamCreateWithFlags(&G.side, hipStreamNonBlocking));
-  for (int i = 0; i < RING; i++) {
-    HIPCHK(hipEventCreateWithFlags(&G.ring_ev[i], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&G.fork_ev[i], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&G.join_ev[i], hipEventDisableTiming));
-  }
+  HIPCHK(hipHostMalloc((void **) &G.h_counts, 2 * RING * QC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   HIPCHK(hipEventCreate(&G.ev0));
   HIPCHK(hipEventCreate(&G.ev1));
   G.blocks_per_cu = trace4_blocks_per_cu();
   if (const char *s = getenv("MIRT_BLOCKS_PER_CU")) {
     int v = atoi(s);
-    if (v >= 1 && v <= 16) G.blocks_per_cu = v;
+    if (v >= 1 && v <= 16) { G.blocks_per_cu = v; G.blocks_forced = true; }
   }
   if (const char *s = getenv("MIRT_SERIAL")) G.serial = atoi(s) != 0;
+  if (const char *s = getenv("MIRT_ONE_PIPE")) G.one_pipe = atoi(s) != 0;
   if (const char *s = getenv("MIRT_STATIC_16TH")) {
     int v = atoi(s);
     if (v >= 0 && v <= 16) G.static_16th = (uint32_t) v;
@@ -180,20 +192,23 @@ int mirt_init(int device) {
 
 void mirt_shutdown(void) {
   if (!G.ready) return;
-  (void) hipStreamSynchronize(G.stream);
-  if (G.side) (void) hipStreamSynchronize(G.side);
-  for (int i = 0; i < RING; i++) {
-    if (G.ring_ev[i]) (void) hipEventDestroy(G.ring_ev[i]);
-    if (G.fork_ev[i]) (void) hipEventDestroy(G.fork_ev[i]);
-    if (G.join_ev[i]) (void) hipEventDestroy(G.join_ev[i]);
+  for (int p = 0; p < 2; p++) {
+    if (G.pstream[p]) (void) hipStreamSynchronize(G.pstream[p]);
+    if (G.pside[p]) (void) hipStreamSynchronize(G.pside[p]);
+    if (G.pipe_ev[p]) (void) hipEventDestroy(G.pipe_ev[p]);
+    for (int i = 0; i < RING; i++) {
+      if (G.ring_ev[p][i]) (void) hipEventDestroy(G.ring_ev[p][i]);
+      if (G.fork_ev[p][i]) (void) hipEventDestroy(G.fork_ev[p][i]);
+      if (G.join_ev[p][i]) (void) hipEventDestroy(G.join_ev[p][i]);
+    }
+    if (G.pside[p]) (void) hipStreamDestroy(G.pside[p]);
   }
-  if (G.side) (void) hipStreamDestroy(G.side);
   if (G.ev0) (void) hipEventDestroy(G.ev0);
   if (G.ev1) (void) hipEventDestroy(G.ev1);
   if (G.h_counts) (void) hipHostFree(G.h_counts);
   for (auto e: G.pool) (void) hipEventDestroy(e);
   G.d_table.release();
-  (void) hipStreamDestroy(G.stream);
+  for (int p = 0; p < 2; p++) if (G.pstream[p]) (void) hipStreamDestroy(G.pstream[p]);
   G = Global();
 }
 
@@ -305,8 +320,8 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
     s->trace_threads = (uint32_t) (G.n_cu * G.blocks_per_cu * TRACE_BLOCK);
     int need = std::max(3 * ((int) s->bvh.depth4 + 2), 7 * ((int) s->bvh.depth8 + 2)) - LDS_STACK + 1;
     s->ovf_depth = (uint32_t) (need > 1 ? need : 1);
-    // two regions: the closest-hit and the shadow launch of an iteration run concurrently
-    ok = s->ovf.ensure(2 * (size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
+    // four regions: the closest-hit and the shadow launch of an iteration run concurrently, in each of two pipes
+    ok = s->ovf.ensure(4 * (size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
   }
   if (!ok) {
     rc = fail(MIRT_E_DEVICE, std::string("scene upload failed: ") + hipGetErrorString(hipGetLastError()));
@@ -429,15 +444,16 @@ int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
   HIPCHK(s->redo_q[0].ensure(n * 4));
   HIPCHK(s->redo_q[1].ensure(kn * 4));
   HIPCHK(s->mf_queue.ensure(n * 4));
-  HIPCHK(s->ctrl.ensure(CTRL_WORDS * 4));
-  HIPCHK(s->ray_stats.ensure(16 * 8));
+  HIPCHK(s->ctrl.ensure(2 * CTRL_WORDS * 4));
+  HIPCHK(s->ray_stats.ensure(2 * 16 * 8));
   return MIRT_OK;
 }
 
-TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal) {
+// `pipe` selects the control block, statistics and stack-overflow regions; `off` is the pipe's first slot (shadow arrays
+// hold K entries per slot, so their offset is K * off), `n_slots` the number of its slots.
+TraceArgs common_args(mirt_scene *s, uint32_t traversal) {
   TraceArgs t;
   memset(&t, 0, sizeof t);
-  uint32_t *ctrl = s->ctrl.as<uint32_t>();
   t.nodes4 = s->nodes4.as<float4>();
   t.nodes2 = s->nodes2.as<float4>();
   t.tris = traversal == 0 ? s->trisf.as<float4>() : s->tris.as<float4>();
@@ -448,60 +464,56 @@ TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal) {
   t.refill_min = G.refill_min;
   t.static_16th = G.static_16th;
   t.big = s->big.as<uint2>();
-  t.ray_o = s->ray_o.as<float4>();
-  t.ray_d = s->ray_d.as<float4>();
-  t.queue = s->ext_queue.as<uint32_t>();
+  t.ovf_depth = s->ovf_depth;
+  return t;
+}
+TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal, int pipe = 0, size_t off = 0) {
+  TraceArgs t = common_args(s, traversal);
+  uint32_t *ctrl = s->ctrl.as<uint32_t>() + (size_t) pipe * CTRL_WORDS;
+  unsigned long long *rs = s->ray_stats.as<unsigned long long>() + (size_t) pipe * 16;
+  t.ray_o = s->ray_o.as<float4>() + off;
+  t.ray_d = s->ray_d.as<float4>() + off;
+  t.queue = s->ext_queue.as<uint32_t>() + off;
   t.qcount = ctrl + CTRL_QCOUNT;
   t.qc_front = QC_EXT_FRONT;
   t.qc_back = QC_EXT_BACK;
   t.qcap = n_slots;
-  t.hit = s->hit.as<float4>();
+  t.hit = s->hit.as<float4>() + off;
   t.work_head = ctrl + CTRL_WORK + 0;
-  t.ovf = s->ovf.as<uint2>();
-  t.ovf_depth = s->ovf_depth;
-  t.redo_queue = s->redo_q[0].as<uint32_t>();
+  t.ovf = s->ovf.as<uint2>() + (size_t) (2 * pipe) * s->ovf_depth * s->trace_threads;
+  t.redo_queue = s->redo_q[0].as<uint32_t>() + off;
   t.redo_count = ctrl + CTRL_REDO + 0;
   t.error_flag = ctrl + CTRL_ERR;
-  t.redo_stat = s->ray_stats.as<unsigned long long>() + 3;
-  t.count_stat = s->ray_stats.as<unsigned long long>() + 4;
+  t.redo_stat = rs + 3;
+  t.count_stat = rs + 4;
   return t;
 }
-TraceArgs shadow_args(mirt_scene *s, uint32_t traversal) {
-  TraceArgs t;
-  memset(&t, 0, sizeof t);
-  uint32_t *ctrl = s->ctrl.as<uint32_t>();
-  t.nodes4 = s->nodes4.as<float4>();
-  t.nodes2 = s->nodes2.as<float4>();
-  t.tris = traversal == 0 ? s->trisf.as<float4>() : s->tris.as<float4>();
-  t.tris2 = s->tris.as<float4>();
-  t.require_unit = traversal == 0 ? 1 : 0;
-  t.nodes8 = s->nodes8q.p;
-  t.spheres = s->has_spheres ? 1 : 0;
-  t.refill_min = G.refill_min;
-  t.static_16th = G.static_16th;
-  t.big = s->big.as<uint2>();
-  t.ray_o = s->sh_o.as<float4>();
-  t.ray_d = s->sh_d.as<float4>();
-  t.queue = s->sh_queue.as<uint32_t>();
+TraceArgs shadow_args(mirt_scene *s, uint32_t traversal, int pipe = 0, size_t koff = 0) {
+  TraceArgs t = common_args(s, traversal);
+  uint32_t *ctrl = s->ctrl.as<uint32_t>() + (size_t) pipe * CTRL_WORDS;
+  unsigned long long *rs = s->ray_stats.as<unsigned long long>() + (size_t) pipe * 16;
+  t.ray_o = s->sh_o.as<float4>() + koff;
+  t.ray_d = s->sh_d.as<float4>() + koff;
+  t.queue = s->sh_queue.as<uint32_t>() + koff;
   t.qcount = ctrl + CTRL_QCOUNT;
   t.qc_front = QC_SHADOW;
   t.qc_back = -1;
-  t.occ = s->sh_occ.as<uint32_t>();
+  t.occ = s->sh_occ.as<uint32_t>() + koff;
   t.work_head = ctrl + CTRL_WORK + WORK_PARTS * CTR_STRIDE;
-  t.ovf = s->ovf.as<uint2>() + (size_t) s->ovf_depth * s->trace_threads;
-  t.ovf_depth = s->ovf_depth;
-  t.redo_queue = s->redo_q[1].as<uint32_t>();
+  t.ovf = s->ovf.as<uint2>() + (size_t) (2 * pipe + 1) * s->ovf_depth * s->trace_threads;
+  t.redo_queue = s->redo_q[1].as<uint32_t>() + koff;
   t.redo_count = ctrl + CTRL_REDO + CTR_STRIDE;
   t.error_flag = ctrl + CTRL_ERR;
-  t.redo_stat = s->ray_stats.as<unsigned long long>() + 3;
-  t.count_stat = s->ray_stats.as<unsigned long long>() + 6;
+  t.redo_stat = rs + 3;
+  t.count_stat = rs + 6;
   return t;
 }
 
 // One trace launch plus the reference walk over the rays it set aside, on `stream`.
 int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, std::vector<Timed> *timed, bool count,
-              hipStream_t stream) {
-  const uint32_t grid = s->trace_threads / TRACE_BLOCK;
+              hipStream_t stream, uint32_t blocks_per_cu = 0) {
+  uint32_t grid = s->trace_threads / TRACE_BLOCK;                       // what the overflow regions are sized for
+  if (blocks_per_cu && blocks_per_cu * (uint32_t) G.n_cu < grid) grid = blocks_per_cu * (uint32_t) G.n_cu;
   Timed tm{any ? 2 : 1, nullptr, nullptr};
   if (timed) {
     tm.a = G.pool_next();
@@ -595,75 +607,125 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
 
   HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
   if (streams > 1) HIPCHK(hipMemsetAsync(s->planes.p, 0, (size_t) streams * w * h * 16, G.stream));
-  HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, 128, G.stream));
-  HIPCHK(hipMemsetAsync(s->ctrl.p, 0, CTRL_WORDS * 4, G.stream));
+  HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, 2 * 128, G.stream));
+  HIPCHK(hipMemsetAsync(s->ctrl.p, 0, 2 * CTRL_WORDS * 4, G.stream));
   HIPCHK(hipEventRecord(evA, G.stream));
+
+  // Pipes: with at least two sample streams the slots are split into two halves that run as independent wavefront loops
+  // on their own streams (see Global).  One pipe otherwise.
+  const int n_pipes = (streams >= 2 && !G.serial && !G.one_pipe && part.n_slots) ? 2 : 1;
+  // with two pipes four persistent launches share the GPU: 4 workgroups per CU each measured best (tools/sweep_env.sh)
+  const uint32_t pipe_blocks = (n_pipes == 2 && !G.blocks_forced) ? 4u : 0u;
+  struct Pipe {
+    RenderArgs a;
+    TraceArgs tc, ts;
+    uint32_t *ctrl;
+    uint64_t it = 0;
+    bool done = false;
+  } pipe[2];
+  for (int p = 0; p < n_pipes; p++) {
+    const uint32_t s_first = n_pipes == 2 ? (p == 0 ? 0 : streams / 2) : 0;
+    const uint32_t s_count = n_pipes == 2 ? (p == 0 ? streams / 2 : streams - streams / 2) : streams;
+    const size_t off = (size_t) s_first * part.n_slots, koff = off * (K ? K : 1);
+    Pipe &pp = pipe[p];
+    pp.ctrl = ctrl + (size_t) p * CTRL_WORDS;
+    pp.a = a;
+    pp.a.n_slots = part.n_slots * s_count;
+    pp.a.stream_first = s_first;
+    pp.a.st += off; pp.a.mask += off; pp.a.total += off; pp.a.accum += off; pp.a.dmask += off;
+    pp.a.ray_o += off; pp.a.ray_d += off; pp.a.hit += off;
+    pp.a.sh_o += koff; pp.a.sh_d += koff; pp.a.sh_c += koff; pp.a.sh_occ += koff;
+    pp.a.ext_queue += off; pp.a.sh_queue += koff; pp.a.mf_queue += off;
+    pp.a.qcount = pp.ctrl + CTRL_QCOUNT;
+    pp.a.mf_count = pp.ctrl + CTRL_MF;
+    pp.a.ray_stats = a.ray_stats + (size_t) p * 16;
+    pp.tc = closest_args(s, pp.a.n_slots, o.traversal, p, off);
+    pp.ts = shadow_args(s, o.traversal, p, koff);
+  }
   uint32_t iters = 0;
   uint64_t n_camera = 0, n_bounced = 0, n_shadow_rays = 0;
   if (part.n_slots) {
-    HIPCHK(launch_init(a, G.stream));
+    if (n_pipes == 2) {                                                  // pipe 1 starts after the clears above
+      HIPCHK(hipEventRecord(G.pipe_ev[0], G.stream));
+      HIPCHK(hipStreamWaitEvent(G.pstream[1], G.pipe_ev[0], 0));
+    }
+    for (int p = 0; p < n_pipes; p++) HIPCHK(launch_init(pipe[p].a, G.pstream[p]));
     const uint64_t max_iters = (uint64_t) a.spp * ((uint64_t) a.max_depth + 3) + 8;
-    const TraceArgs tc = closest_args(s, a.n_slots, o.traversal), ts = shadow_args(s, o.traversal);
-    bool done = false;
-    for (uint64_t it = 0; !done; it++) {
-      if (it >= max_iters + RING) {
-        (void) hipStreamSynchronize(G.stream);
-        return fail(MIRT_E_DEVICE, "wavefront loop did not terminate");
-      }
-      HIPCHK(hipMemsetAsync(ctrl, 0, CTRL_ERR * 4, G.stream));          // queue counters, work heads, redo counters
-      Timed tl{0, nullptr, nullptr};
-      if (profile) {
-        tl.a = G.pool_next();
-        tl.b = G.pool_next();
-        if (!tl.a || !tl.b) return fail(MIRT_E_DEVICE, "could not create timing events");
-        HIPCHK(hipEventRecord(tl.a, G.stream));
-      }
-      HIPCHK(launch_logic(a, false, G.stream));
-      if (s->has_microfacet) HIPCHK(launch_logic(a, true, G.stream));
-      if (profile) {
-        HIPCHK(hipEventRecord(tl.b, G.stream));
-        timed.push_back(tl);
-      }
-      const int slot = (int) (it % RING);
-      HIPCHK(hipMemcpyAsync(G.h_counts + slot * QC_WORDS, ctrl + CTRL_QCOUNT, QC_WORDS * 4, hipMemcpyDeviceToHost, G.stream));
-      HIPCHK(hipEventRecord(G.ring_ev[slot], G.stream));
-      // The two traversals of an iteration are independent: the shadow rays go to the side stream, so the tail of one
-      // launch (a few long rays, the GPU mostly idle) is filled by the other.  MIRT_SERIAL=1 keeps one stream.
-      const bool fork = K != 0 && !G.serial;
-      if (fork) {
-        HIPCHK(hipEventRecord(G.fork_ev[slot], G.stream));
-        HIPCHK(hipStreamWaitEvent(G.side, G.fork_ev[slot], 0));
-        rc = run_trace(s, ts, true, o.traversal, profile ? &timed : nullptr, counting, G.side);
+    bool all_done = false;
+    while (!all_done) {
+      all_done = true;
+      for (int p = 0; p < n_pipes; p++) {
+        Pipe &pp = pipe[p];
+        if (pp.done) continue;
+        all_done = false;
+        hipStream_t main = G.pstream[p], side = G.pside[p];
+        uint32_t *hcounts = G.h_counts + (size_t) p * RING * QC_WORDS;
+        const uint64_t it = pp.it++;
+        if (it >= max_iters + RING) {
+          (void) hipDeviceSynchronize();
+          return fail(MIRT_E_DEVICE, "wavefront loop did not terminate");
+        }
+        HIPCHK(hipMemsetAsync(pp.ctrl, 0, CTRL_ERR * 4, main));          // queue counters, work heads, redo counters
+        Timed tl{0, nullptr, nullptr};
+        if (profile) {
+          tl.a = G.pool_next();
+          tl.b = G.pool_next();
+          if (!tl.a || !tl.b) return fail(MIRT_E_DEVICE, "could not create timing events");
+          HIPCHK(hipEventRecord(tl.a, main));
+        }
+        HIPCHK(launch_logic(pp.a, false, main));
+        if (s->has_microfacet) HIPCHK(launch_logic(pp.a, true, main));
+        if (profile) {
+          HIPCHK(hipEventRecord(tl.b, main));
+          timed.push_back(tl);
+        }
+        const int slot = (int) (it % RING);
+        HIPCHK(hipMemcpyAsync(hcounts + slot * QC_WORDS, pp.ctrl + CTRL_QCOUNT, QC_WORDS * 4, hipMemcpyDeviceToHost, main));
+        HIPCHK(hipEventRecord(G.ring_ev[p][slot], main));
+        // The two traversals of an iteration are independent: the shadow rays go to the side stream, so the tail of one
+        // launch (a few long rays, the GPU mostly idle) is filled by the other.  MIRT_SERIAL=1 keeps one stream.
+        const bool fork = K != 0 && !G.serial;
+        if (fork) {
+          HIPCHK(hipEventRecord(G.fork_ev[p][slot], main));
+          HIPCHK(hipStreamWaitEvent(side, G.fork_ev[p][slot], 0));
+          rc = run_trace(s, pp.ts, true, o.traversal, profile ? &timed : nullptr, counting, side, pipe_blocks);
+          if (rc) return rc;
+          HIPCHK(hipEventRecord(G.join_ev[p][slot], side));
+        }
+        rc = run_trace(s, pp.tc, false, o.traversal, profile ? &timed : nullptr, counting, main, pipe_blocks);
         if (rc) return rc;
-        HIPCHK(hipEventRecord(G.join_ev[slot], G.side));
+        if (K && !fork) {
+          rc = run_trace(s, pp.ts, true, o.traversal, profile ? &timed : nullptr, counting, main, pipe_blocks);
+          if (rc) return rc;
+        }
+        if (fork) HIPCHK(hipStreamWaitEvent(main, G.join_ev[p][slot], 0));
+        if (p == 0) iters++;
+        if (it + 1 >= RING - 1) {                                        // look at the counters of RING-2 iterations ago
+          const uint64_t old = it + 1 - (RING - 1);
+          const uint32_t *hc = hcounts + (old % RING) * QC_WORDS;
+          HIPCHK(hipEventSynchronize(G.ring_ev[p][old % RING]));
+          // a slot that is not finished leaves a ray in one of the queues: empty queues = this half is complete (and
+          // every later iteration already launched found them empty too)
+          n_camera += hc[QC_EXT_FRONT];
+          n_bounced += hc[QC_EXT_BACK];
+          n_shadow_rays += hc[QC_SHADOW];
+          if (hc[QC_EXT_FRONT] + hc[QC_EXT_BACK] + hc[QC_SHADOW] == 0) pp.done = true;
+        }
       }
-      rc = run_trace(s, tc, false, o.traversal, profile ? &timed : nullptr, counting, G.stream);
-      if (rc) return rc;
-      if (K && !fork) {
-        rc = run_trace(s, ts, true, o.traversal, profile ? &timed : nullptr, counting, G.stream);
-        if (rc) return rc;
-      }
-      if (fork) HIPCHK(hipStreamWaitEvent(G.stream, G.join_ev[slot], 0));
-      iters++;
-      if (it + 1 >= RING - 1) {                                          // look at the counters of RING-2 iterations ago
-        const uint64_t old = it + 1 - (RING - 1);
-        const uint32_t *hc = G.h_counts + (old % RING) * QC_WORDS;
-        HIPCHK(hipEventSynchronize(G.ring_ev[old % RING]));
-        // a slot that is not finished leaves a ray in one of the queues: empty queues = frame complete (and every later
-        // iteration already launched found them empty too)
-        n_camera += hc[QC_EXT_FRONT];
-        n_bounced += hc[QC_EXT_BACK];
-        n_shadow_rays += hc[QC_SHADOW];
-        if (hc[QC_EXT_FRONT] + hc[QC_EXT_BACK] + hc[QC_SHADOW] == 0) done = true;
-      }
+    }
+    if (n_pipes == 2) {
+      HIPCHK(hipEventRecord(G.pipe_ev[1], G.pstream[1]));
+      HIPCHK(hipStreamWaitEvent(G.stream, G.pipe_ev[1], 0));
     }
   }
   if (streams > 1 && part.n_slots)
     HIPCHK(launch_sum_planes(s->planes.as<float4>(), streams, w * h, (float4 *) accum_dev, G.stream));
   HIPCHK(hipEventRecord(evB, G.stream));
   HIPCHK(hipEventSynchronize(evB));
-  uint32_t err = 0;
+  uint32_t err = 0, err1 = 0;
   HIPCHK(hipMemcpy(&err, ctrl + CTRL_ERR, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&err1, ctrl + CTRL_WORDS + CTRL_ERR, 4, hipMemcpyDeviceToHost));
+  err |= err1;
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, evA, evB));
   (void) hipEventDestroy(evA);
@@ -676,8 +738,9 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     n_kind[t.kind]++;
   }
   if (stats) {
-    unsigned long long rs[16] = {0};
-    HIPCHK(hipMemcpy(rs, s->ray_stats.p, 128, hipMemcpyDeviceToHost));
+    unsigned long long rs[32] = {0};
+    HIPCHK(hipMemcpy(rs, s->ray_stats.p, 256, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 16; k++) rs[k] += rs[16 + k];                    // the two pipes' counters
     memset(stats, 0, sizeof *stats);
     stats->closest_rays = n_camera + n_bounced;
     stats->shadow_rays = n_shadow_rays;

@@ -74,7 +74,7 @@ __global__ void k_init(RenderArgs a) {
 __device__ __forceinline__ void stream_share(const RenderArgs &a, uint32_t s, uint32_t &stream, uint32_t &first, uint32_t &count) {
   stream = 0; first = 0; count = a.spp;
   if (a.streams > 1) {
-    stream = s / a.n_pixel_slots;
+    stream = a.stream_first + s / a.n_pixel_slots;
     const uint32_t per = a.spp / a.streams;
     first = stream * per;
     count = (stream == a.streams - 1) ? a.spp - per * (a.streams - 1) : per;

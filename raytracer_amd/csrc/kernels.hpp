@@ -27,6 +27,7 @@ constexpr int WORK_PARTS = 8;        // a trace launch splits its queue into thi
 struct RenderArgs {
   uint32_t n_slots, width, height, tiles_x, tiles_y, tile_rank, tile_world;
   uint32_t rng_mode, seed, sample_begin;
+  uint32_t stream_first;                  // the stream of this launch's slot 0 (a pipe renders a contiguous range of streams)
   uint32_t n_pixel_slots, streams;        // streams > 1: slot = stream * n_pixel_slots + pixel slot (mirt_options.streams)
   uint32_t spp, spl, batch, max_depth, adaptive, glass_int_abs, n_lights;
   float tol;
