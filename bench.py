@@ -191,7 +191,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (procedural stand-in scene: the reference's .obj meshes are absent)",
             "config": {"workload": f"{args.workload} {sd.n} tris, {w}x{h}, {args.spp} spp, depth {args.depth}, "
-                                   f"2 lights, rng {'counter' if opt['rng_mode'] else 'xorshift'}, "
+                                   f"{len(sd.lights)} light{'s' if len(sd.lights) != 1 else ''}, rng {'counter' if opt['rng_mode'] else 'xorshift'}, "
                                    f"traversal {args.traversal}, {opt['streams']} sample streams",
                        "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
                        "scene_build_s": build_s},
