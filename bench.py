@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=8,
                     help="sample streams per pixel in flight (mirt_options.streams): same samples, fewer and larger wavefront "
                          "iterations; 1 = one path per pixel at a time, the reference's order of summation")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL, one GPU per rank (what the driver runs); gloo = rehearsal of the N > 1 path on a box "
+                         "with fewer GPUs than ranks: ranks share the GPUs and the buffers are summed through host memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -105,13 +108,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
 
     from raytracer_amd import capi, scenes
 
@@ -128,6 +137,8 @@ def main():
     if world > 1 and args.partition == "tile":
         opt.update(tile_rank=rank, tile_world=world)
     elif world > 1:
+        if args.spp < world:
+            raise SystemExit("spp partition needs at least one sample per rank: use --partition tile")
         per = args.spp // world
         opt.update(rng_mode=1, sample_begin=rank * per, sample_count=per if rank < world - 1 else args.spp - per * (world - 1))
     kw = dict(spp=args.spp, spl=1, batch=args.spp + 1, tol=0.0, depth=args.depth)   # fixed spp: no adaptive stop
@@ -140,9 +151,15 @@ def main():
 
     def step():
         st = scene.render_accum(w, h, accum.data_ptr(), **kw, **opt)
-        if dist is not None:
+        if dist is not None and args.backend == "nccl":
             dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
             torch.cuda.synchronize()
+        elif dist is not None:
+            host = accum.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                accum.copy_(host)
+                torch.cuda.synchronize()
         if rank == 0:
             capi.tonemap(accum.data_ptr(), w, h)          # film in host memory
         return st
@@ -156,7 +173,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     rays = sum(s["closest_rays"] + s["shadow_rays"] for s in stats)
-    tl = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    tl = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         tmax = tl.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
