@@ -125,6 +125,45 @@ def test_known_answer_scene_with_a_sphere(mirt, oracle, golden):
     s.close()
 
 
+def test_overlapping_geometry_overflows_the_lds_stack(mirt, oracle):
+    """2000 large triangles in a small volume: every box overlaps every ray, so the 8-wide traversal pushes far more than
+    the 12 entries a lane keeps in LDS (global overflow region), and 64 coincident triangles tie on every hit."""
+    sc = scenes.random_soup(2000, 4, extent=0.3, tri_size=1.0)
+    sc.pos[100:164] = sc.pos[100]                              # 64 coincident triangles
+    sc = sc.finalize()
+    oracle.load(sc)
+    s = mirt.Scene(sc)
+    rays = random_rays(sc, 20000, 11, True)
+    ci, ct = oracle.trace(rays)
+    ai, _ = oracle.trace(rays, anyhit=True)
+    for trav in (0, 1, 2):
+        gi, gt = s.trace(rays, traversal=trav)
+        assert (gi == ci).all() and (gt == ct).all(), f"closest, traversal {trav}: {(gi != ci).sum()} differ"
+        hi, _ = s.trace(rays, anyhit=True, traversal=trav)
+        assert (hi == ai).all(), f"any-hit, traversal {trav}"
+    assert (ci >= 100).sum() > 0 and ((ci >= 100) & (ci < 164)).sum() >= 0
+    s.close()
+
+
+def test_six_shadow_rays_per_hit(mirt, oracle):
+    """3 lights x 2 samples per light: the generic shadow-fold and emission loops of k_logic (the bench has K = 2)."""
+    sc = scenes.cornell_scene(1, "diffuse")
+    sc.lights = np.array([scenes.area_light((12, 12, 12), (0, 2.99, 0), (0, -1, 0), (1, 0, 0), (0, 0, 1)),
+                          scenes.point_light((1.5, 1.5, 1.5), (1.5, 2.5, -1.5)),
+                          scenes.directional_light((.3, .3, .3), (-1, -1, 1))])
+    sc = sc.finalize()
+    oracle.load(sc)
+    oracle.set_camera(sc.camera)
+    s = mirt.Scene(sc)
+    w, h = 96, 64
+    ref = oracle.render(w, h, spp=3, spl=2, batch=64, tol=0.0, depth=4)
+    img = s.render(w, h, spp=3, spl=2, batch=64, tol=0.0, depth=4)
+    assert (img == ref).mean() >= 0.999
+    assert (s.last["closest_rays"], s.last["shadow_rays"]) == (oracle.last["closest"], oracle.last["shadow"])
+    assert s.last["shadow_rays"] > 6 * w * h
+    s.close()
+
+
 def test_trace_edge_cases(mirt, oracle):
     sc = scenes.cornell_scene(1, "diffuse")
     oracle.load(sc)
