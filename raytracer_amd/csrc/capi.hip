@@ -551,7 +551,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   if (o.traversal == 0 && !s->fast_ok) o.traversal = 1;
   if (o.tile_world > 1 && o.tile_rank >= o.tile_world) return fail(MIRT_E_ARG, "tile_rank >= tile_world");
   uint32_t streams = o.streams > 1 ? o.streams : 1;
-  const bool sliced = o.sample_count != 0 || o.sample_begin != 0 || streams > 1;
+  const bool sliced = o.sample_count != 0 || o.sample_begin != 0 || streams > 1 || (o.flags & 4u);
   if (sliced && o.rng_mode != 1)
     return fail(MIRT_E_ARG, "spp slices and sample streams need rng_mode 1 (the xorshift stream is sequential per pixel)");
   if (streams > 16) return fail(MIRT_E_ARG, "at most 16 sample streams");
@@ -569,7 +569,11 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
 
   int rc = ensure_work(s, (uint32_t) total_slots, K);
   if (rc) return rc;
-  if (streams > 1) HIPCHK(s->planes.ensure((size_t) streams * w * h * 16));
+  // progressive pass (flags bit 2): the samples are added to what accum_dev already holds, through the plane buffer
+  const bool accumulate = (o.flags & 4u) != 0;
+  const bool via_planes = streams > 1 || accumulate;
+  if (accumulate && o.rng_mode != 1) return fail(MIRT_E_ARG, "progressive passes need rng_mode 1");
+  if (via_planes) HIPCHK(s->planes.ensure((size_t) streams * w * h * 16));
 
   RenderArgs a;
   memset(&a, 0, sizeof a);
@@ -591,7 +595,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   uint32_t *ctrl = s->ctrl.as<uint32_t>();
   a.qcount = ctrl + CTRL_QCOUNT;
   a.ray_stats = s->ray_stats.as<unsigned long long>();
-  a.out_accum = streams > 1 ? s->planes.as<float4>() : (float4 *) accum_dev;
+  a.out_accum = via_planes ? s->planes.as<float4>() : (float4 *) accum_dev;
   a.tri_nrm = s->tri_nrm.as<float4>(); a.mats = s->mats.as<float4>(); a.lights = s->lights.as<float>();
   a.mf_queue = s->mf_queue.as<uint32_t>(); a.mf_count = ctrl + CTRL_MF;
 
@@ -605,8 +609,8 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   HIPCHK(hipEventCreate(&evA));
   HIPCHK(hipEventCreate(&evB));
 
-  HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
-  if (streams > 1) HIPCHK(hipMemsetAsync(s->planes.p, 0, (size_t) streams * w * h * 16, G.stream));
+  if (!accumulate) HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
+  if (via_planes) HIPCHK(hipMemsetAsync(s->planes.p, 0, (size_t) streams * w * h * 16, G.stream));
   HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, 2 * 128, G.stream));
   HIPCHK(hipMemsetAsync(s->ctrl.p, 0, 2 * CTRL_WORDS * 4, G.stream));
   HIPCHK(hipEventRecord(evA, G.stream));
@@ -718,8 +722,8 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
       HIPCHK(hipStreamWaitEvent(G.stream, G.pipe_ev[1], 0));
     }
   }
-  if (streams > 1 && part.n_slots)
-    HIPCHK(launch_sum_planes(s->planes.as<float4>(), streams, w * h, (float4 *) accum_dev, G.stream));
+  if (via_planes && part.n_slots)
+    HIPCHK(launch_sum_planes(s->planes.as<float4>(), streams, w * h, (float4 *) accum_dev, accumulate ? 1 : 0, G.stream));
   HIPCHK(hipEventRecord(evB, G.stream));
   HIPCHK(hipEventSynchronize(evB));
   uint32_t err = 0, err1 = 0;

@@ -1155,13 +1155,17 @@ __global__ void k_iota(uint32_t *q, uint32_t n) {
 
 // Sample streams: the per-stream partial sums (sum rgb, sample count) are added in stream order, so the result does not
 // depend on scheduling.
-__global__ void k_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n, float4 *out) {
+__global__ void k_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n, float4 *out, int add_to_out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 acc = planes[i];
   for (uint32_t k = 1; k < n_planes; k++) {
     const float4 v = planes[(size_t) k * n + i];
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  if (add_to_out) {                                       // progressive pass: the buffer already holds earlier passes
+    const float4 v = out[i];
+    acc.x = v.x + acc.x; acc.y = v.y + acc.y; acc.z = v.z + acc.z; acc.w = v.w + acc.w;
   }
   out[i] = acc;
 }
@@ -1228,8 +1232,8 @@ hipError_t launch_iota(uint32_t *q, uint32_t n, hipStream_t st) {
   LAUNCH_CHECK();
   return hipSuccess;
 }
-hipError_t launch_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n, float4 *out, hipStream_t st) {
-  k_sum_planes<<<(n + 255) / 256, 256, 0, st>>>(planes, n_planes, n, out);
+hipError_t launch_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n, float4 *out, int add_to_out, hipStream_t st) {
+  k_sum_planes<<<(n + 255) / 256, 256, 0, st>>>(planes, n_planes, n, out, add_to_out);
   LAUNCH_CHECK();
   return hipSuccess;
 }

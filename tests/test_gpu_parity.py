@@ -341,6 +341,33 @@ def test_sample_streams_render_the_same_samples(mirt):
     s.close()
 
 
+def test_progressive_passes_add_up(mirt):
+    """progressive output = passes of a few samples added into one float buffer (flags bit 2), a
+    tonemapped snapshot after each.  Four passes of 4 spp equal, bit for bit, the sum of the same four slices rendered
+    separately, and the film of the last snapshot is the 16-spp film (>= 99.9 %: the sum is associated per pass)."""
+    torch = pytest.importorskip("torch")
+    sc = scenes.cornell_scene(2, "mixed")
+    s = mirt.Scene(sc)
+    w, h = 160, 96
+    kw = dict(spp=16, spl=1, batch=17, tol=0.0, depth=5, rng_mode=1, seed=3)
+    prog = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    manual = torch.zeros_like(prog)
+    part = torch.zeros_like(prog)
+    snaps = []
+    for p in range(4):
+        s.render_accum(w, h, prog.data_ptr(), sample_begin=4 * p, sample_count=4, accumulate=p > 0, streams=2, **kw)
+        snaps.append(mirt.tonemap(prog.data_ptr(), w, h))
+        s.render_accum(w, h, part.data_ptr(), sample_begin=4 * p, sample_count=4, streams=2, **kw)
+        manual += part
+        assert (prog[..., 3] == 4 * (p + 1)).all()
+    assert torch.equal(prog, manual)
+    full = torch.zeros_like(prog)
+    s.render_accum(w, h, full.data_ptr(), **kw)
+    assert (snaps[-1] == mirt.tonemap(full.data_ptr(), w, h)).mean() >= 0.999
+    assert np.abs(snaps[0].astype(int) - snaps[-1].astype(int)).mean() > 0.5          # the first snapshot is noisier
+    s.close()
+
+
 def test_device_tonemap_and_bmp(mirt, golden, tmp_path):
     import torch
 
