@@ -341,6 +341,68 @@ def test_sample_streams_render_the_same_samples(mirt):
     s.close()
 
 
+def test_full_size_properties_on_the_bench_workload(mirt):
+    """BASELINE size (conference* 320 k triangles, 1920x1080), where the CPU oracle would take minutes: properties that do not
+    need it.  (1) all three traversals agree bit for bit on 2 M primary rays (mode 2 IS the reference's walk); (2) the frame
+    is deterministic; (3) the tile partition sums to it bit for bit; (4) spp slices, sample streams and progressive passes
+    trace exactly the same rays and agree to float re-association."""
+    torch = pytest.importorskip("torch")
+    sc = scenes.conference_scene()
+    w, h, spp = 1920, 1080, 8
+    sc.camera = sc.camera.for_aspect(w, h)
+    s = mirt.Scene(sc)
+    i2, t2 = s.primary_hits(w, h, traversal=2)
+    for trav in (0, 1):
+        i, t = s.primary_hits(w, h, traversal=trav)
+        assert (i == i2).all() and (t == t2).all(), f"traversal {trav}: {(i != i2).sum()} of {w * h} primary hits differ"
+    assert (i2 >= 0).all()                                           # closed room
+    kw = dict(spp=spp, spl=1, batch=spp + 1, tol=0.0, depth=8, rng_mode=1)
+    full = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    st = dict(s.render_accum(w, h, full.data_ptr(), **kw))
+    rays = (st["closest_rays"], st["shadow_rays"], st["paths"])
+    assert st["paths"] == w * h * spp and st["traversal_used"] == 0
+    again = torch.zeros_like(full)
+    s.render_accum(w, h, again.data_ptr(), **kw)
+    assert torch.equal(full, again)
+    tiles = torch.zeros_like(full)
+    part = torch.zeros_like(full)
+    n = [0, 0, 0]
+    for r in range(2):
+        stp = s.render_accum(w, h, part.data_ptr(), tile_rank=r, tile_world=2, **kw)
+        tiles += part
+        n = [a + b for a, b in zip(n, (stp["closest_rays"], stp["shadow_rays"], stp["paths"]))]
+    assert torch.equal(full, tiles) and tuple(n) == rays
+    for variant in (dict(streams=8), dict(streams=3)):
+        acc = torch.zeros_like(full)
+        stv = s.render_accum(w, h, acc.data_ptr(), **kw, **variant)
+        assert (stv["closest_rays"], stv["shadow_rays"], stv["paths"]) == rays
+        assert torch.allclose(acc, full, rtol=2e-5, atol=1e-6)
+    prog = torch.zeros_like(full)
+    n = [0, 0, 0]
+    for p in range(2):
+        stp = s.render_accum(w, h, prog.data_ptr(), sample_begin=4 * p, sample_count=4, accumulate=p > 0, streams=4, **kw)
+        n = [a + b for a, b in zip(n, (stp["closest_rays"], stp["shadow_rays"], stp["paths"]))]
+    assert tuple(n) == rays and torch.allclose(prog, full, rtol=2e-5, atol=1e-6)
+    film = mirt.tonemap(full.data_ptr(), w, h)
+    assert (mirt.tonemap(prog.data_ptr(), w, h) == film).mean() >= 0.999
+    assert 20 < film.mean() < 235
+    s.close()
+
+
+def test_one_million_triangles_all_traversals_agree(mirt):
+    """buddha* (1 046 530 triangles, BASELINE configs[2] geometry) at 1080p: the ordered traversal of the quantised tree, the
+    folded reference tree and the reference walk give the same 2 M primary hits and t bits."""
+    sc = scenes.blob_scene(1024, 512, "buddha*")
+    sc.camera = sc.camera.for_aspect(1920, 1080)
+    s = mirt.Scene(sc)
+    i2, t2 = s.primary_hits(1920, 1080, traversal=2)
+    for trav in (0, 1):
+        i, t = s.primary_hits(1920, 1080, traversal=trav)
+        assert (i == i2).all() and (t == t2).all(), f"traversal {trav}: {(i != i2).sum()} differ"
+    assert 0.2 < (i2 >= 0).mean() < 1.0
+    s.close()
+
+
 def test_progressive_passes_add_up(mirt):
     """progressive output = passes of a few samples added into one float buffer (flags bit 2), a
     tonemapped snapshot after each.  Four passes of 4 spp equal, bit for bit, the sum of the same four slices rendered
