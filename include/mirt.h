@@ -69,8 +69,11 @@ typedef struct mirt_options {
   uint32_t rng_mode;        /* 0 = reference xorshift32 stream per pixel (util/sampler.cuh:8-15, renderer.cuh:50-51);
                                1 = counter-based Philox2x32-10 keyed by (pixel, sample, seed): needed for spp slices */
   uint32_t seed;            /* rng_mode 0: xor-ed into the pixel seed (0 = the reference); rng_mode 1: global seed */
-  uint32_t traversal;       /* 0 = ordered wide-BVH traversal (fast path; see DESIGN.md "tie rule")
-                               1 = wide BVH visited in the reference's DFS order (bit-exact with bvh.cuh:78-107)
+  uint32_t traversal;       /* 0 = ordered traversal of the library's own 8-wide SAH tree; rays whose outcome could hinge on
+                                   the reference's own box tests are re-traced by the reference walk, so results equal the
+                                   reference's
+                               1 = the reference's tree folded to 4-wide nodes, visited in the reference's DFS order
+                                   (bit-exact with bvh.cuh:78-107 by construction)
                                2 = the reference's BVH2 walked as the reference does (cross-check) */
   uint32_t tile_rank;       /* tile partition: this process renders 8x8 tiles t with t % tile_world == tile_rank */
   uint32_t tile_world;      /* 0 or 1 = whole image */
@@ -120,7 +123,8 @@ const char *mirt_version(void);
 /* Replaces renderer.cuh:136-146 (BVHAccel ctor bvh.cuh:177-225, to_optimized_bvh bvh.cuh:231-290, to_cuda bvh.cuh:112-145).
  * tri_pos / tri_nrm: n_tris x 9 floats (p1 p2 p3 / n1 n2 n3, scene/primitives.cuh:23-26); tri_mat: material index per
  * triangle.  The reference's BVH2 is rebuilt bit for bit on the host (its flat primitive order defines hit indices), then
- * collapsed into the 128-byte wide nodes the kernels walk. */
+ * folded into the wide nodes of traversal 1; the ordered traversal's own tree (binned SAH, 8-wide quantised nodes) is built
+ * next to it over the same primitives. */
 int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, uint32_t n_tris,
                       const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights, uint32_t n_lights,
                       uint32_t leaf_size, mirt_scene **out);

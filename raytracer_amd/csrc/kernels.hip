@@ -6,8 +6,8 @@
 //   k_trace_fast<..>  traversal 0: persistent-thread ordered traversal of the 8-wide quantised SAH tree (LDS stack)
 //   k_redo<ANY>       the reference walk, one wave per ray, for the rays k_trace_fast sets aside
 //   k_trace4<ANY,..>  traversal 1: the reference tree folded to 4-wide nodes, reference visiting order (exact)
-//   k_trace2<ANY>     the reference's own BVH2 walk (bvh.cuh:49-107), used for the `traversal = 2` cross-check and
-//                     for the few rays whose slab / hit arithmetic goes non-finite (results then depend on visit order)
+//   k_trace2<ANY>     traversal 2: the reference's own BVH2 walk (bvh.cuh:49-107), one ray per lane (cross-check)
+//   k_sum_planes      sample streams / progressive passes: partial sums added in a fixed order
 //   k_tonemap         film: divide + threshold-table tonemap (util/image.cuh:36-48)
 //
 // Built with -ffp-contract=off: the reference's g++ build never fuses a*b+c.
