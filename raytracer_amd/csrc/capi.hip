@@ -76,7 +76,7 @@ struct Global {
   bool blocks_forced = false;           // MIRT_BLOCKS_PER_CU given
   float table[256];
   bool table_exact = false;
-  DevBuf d_table;
+  DevBuf d_table, d_rgb;
   uint32_t *h_counts = nullptr;          // pinned: 2 pipes x RING x QC_WORDS
   hipEvent_t ring_ev[2][RING] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -208,6 +208,7 @@ void mirt_shutdown(void) {
   if (G.h_counts) (void) hipHostFree(G.h_counts);
   for (auto e: G.pool) (void) hipEventDestroy(e);
   G.d_table.release();
+  G.d_rgb.release();
   for (int p = 0; p < 2; p++) if (G.pstream[p]) (void) hipStreamDestroy(G.pstream[p]);
   G = Global();
 }
@@ -785,12 +786,10 @@ int mirt_tonemap(const void *accum_dev, uint32_t width, uint32_t height, int32_t
   if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
   if (!accum_dev || !rgb_out || !width || !height) return fail(MIRT_E_ARG, "null / empty argument");
   const size_t n = (size_t) width * height;
-  DevBuf rgb;
-  HIPCHK(rgb.ensure(n * 12));
-  hipError_t e = launch_tonemap(accum_dev, (uint32_t) n, G.d_table.as<float>(), rgb.as<int32_t>(), G.stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(rgb_out, rgb.p, n * 12, hipMemcpyDeviceToHost, G.stream);
+  HIPCHK(G.d_rgb.ensure(n * 12));                                        // kept between calls
+  hipError_t e = launch_tonemap(accum_dev, (uint32_t) n, G.d_table.as<float>(), G.d_rgb.as<int32_t>(), G.stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(rgb_out, G.d_rgb.p, n * 12, hipMemcpyDeviceToHost, G.stream);
   if (e == hipSuccess) e = hipStreamSynchronize(G.stream);
-  rgb.release();
   if (e != hipSuccess) return fail(MIRT_E_DEVICE, std::string("tonemap: ") + hipGetErrorString(e));
   return MIRT_OK;
 }
