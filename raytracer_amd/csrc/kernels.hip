@@ -918,11 +918,16 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
       tri_n = (ref >> LEAF_COUNT_SHIFT) & 15u;              // the SAH tree has no oversized leaves
     }
   };
+  // (a stack deeper than LDS + overflow region cannot happen for the tree the region was sized for; if it does, the entry
+  // lands on the last slot, the ray is flagged and the launch reports it once the ray ends)
+  bool too_deep = false;
+  const int sp_max = LDS_STACK + (int) a.ovf_depth - 1;
   auto push = [&](uint32_t ref, float tmn) {
-    if (sp < LDS_STACK) lds_stack[sp * TRACE_BLOCK + tid] = make_uint2(ref, f2u(tmn));
-    else if (sp < LDS_STACK + (int) a.ovf_depth) a.ovf[(size_t) (sp - LDS_STACK) * nthreads + gtid] = make_uint2(ref, f2u(tmn));
-    else { atomicOr(a.error_flag, 2u); return; }
-    sp++;
+    too_deep = too_deep || sp > sp_max;
+    const int at = sp > sp_max ? sp_max : sp;
+    if (at < LDS_STACK) lds_stack[at * TRACE_BLOCK + tid] = make_uint2(ref, f2u(tmn));
+    else a.ovf[(size_t) (at - LDS_STACK) * nthreads + gtid] = make_uint2(ref, f2u(tmn));
+    sp = at + 1;
   };
   auto pop = [&]() {
     uint32_t next = CHILD_EMPTY;
@@ -1087,6 +1092,10 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
 
     // ---------------------------------------------------------------- ray finished
     if (active && cur == CHILD_EMPTY) {
+      if (too_deep) {
+        atomicOr(a.error_flag, 2u);
+        too_deep = false;
+      }
       if (ANY) {
         a.occ[r.id] = 0u;
         if (a.any_t) a.any_t[r.id] = r.best_t;
