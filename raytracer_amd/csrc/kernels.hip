@@ -893,17 +893,23 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
   // static_16th/16 of the queue is cut into one slice per workgroup, handed out to its waves through an LDS counter; the
   // rest is a pool of WORK_PARTS ranges with global counters that balances the load at the end, and a workgroup probes a
   // dry range only once (LDS bitmask).
+  // A launch with few rays (the tail of a frame, a small image) uses only as many workgroups as it has rays for, one ray
+  // per lane; the others leave at once instead of queueing up at the pool counters (measured: 125 us -> ~20 us for a
+  // launch of 4 k rays).
   __shared__ uint32_t s_next, s_dry;
-  const uint32_t per_blk = (uint32_t) (((uint64_t) total * a.static_16th / 16u) / gridDim.x) & ~63u;
+  const uint32_t want_blk = (total + TRACE_BLOCK - 1) / TRACE_BLOCK;
+  const uint32_t n_blk = want_blk < gridDim.x ? (want_blk ? want_blk : 1u) : gridDim.x;
+  if (blockIdx.x >= n_blk) return;
+  const uint32_t per_blk = (uint32_t) (((uint64_t) total * a.static_16th / 16u) / n_blk) & ~63u;
   const uint32_t slice_end = (blockIdx.x + 1) * per_blk;
-  const uint32_t pool_lo = gridDim.x * per_blk, pool_total = total - pool_lo;
+  const uint32_t pool_lo = n_blk * per_blk, pool_total = total - pool_lo;
   if (tid == 0) {
     s_next = blockIdx.x * per_blk;
     s_dry = 0;
   }
   __syncthreads();
   const uint32_t psz = ((pool_total + WORK_PARTS - 1) / WORK_PARTS + 63u) & ~63u;     // pool positions per range
-  uint32_t chunk = (pool_total / (gridDim.x * (TRACE_BLOCK / 64) * 2u)) & ~31u;
+  uint32_t chunk = (pool_total / (n_blk * (TRACE_BLOCK / 64) * 2u)) & ~31u;
   chunk = chunk < 32u ? 32u : (chunk > 256u ? 256u : chunk);
   uint32_t w_next = 0, w_end = 0, part = blockIdx.x & (WORK_PARTS - 1), parts_tried = 0;
   bool slice_done = (per_blk == 0);
