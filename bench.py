@@ -50,7 +50,7 @@ def parse():
                     help="N > 1: spp slices (default: the wavefront loop runs spp/N times fewer, full-size iterations; 0.83-0.97 "
                          "per-rank efficiency measured with tools/part_probe.py) or interleaved 8x8 tiles (bit-identical to one "
                          "GPU, but every iteration shrinks to 1/N of the rays: 0.23 at N = 8)")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=4,
                     help="sample streams per pixel in flight (mirt_options.streams): same samples, fewer and larger wavefront "
                          "iterations; 1 = one path per pixel at a time, the reference's order of summation")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -133,7 +133,8 @@ def main():
     w, h = args.width, args.height
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
 
-    opt = dict(rng_mode=args.rng, traversal=args.traversal, profile=True, streams=args.streams if args.rng == 1 else 0)
+    # the timed steps carry HIP events around the dominant kernel's launches only (every event pair costs a little)
+    opt = dict(rng_mode=args.rng, traversal=args.traversal, profile_closest=True, streams=args.streams if args.rng == 1 else 0)
     if world > 1 and args.partition == "tile":
         opt.update(tile_rank=rank, tile_world=world)
     elif world > 1:
@@ -185,6 +186,8 @@ def main():
         # traversal work per ray (counting build of the same kernels, one untimed reduced-spp frame)
         cnt = scene.render_accum(w, h, accum.data_ptr(), spp=min(4, args.spp), spl=1, batch=args.spp + 1, tol=0.0,
                                  depth=args.depth, **{**opt, "count": True, "sample_count": 0, "sample_begin": 0})
+        # one more untimed frame with events around every launch, for the per-kernel split
+        split = scene.render_accum(w, h, accum.data_ptr(), **kw, **{**opt, "profile": True, "profile_closest": False})
         n_node = cnt["closest_node_visits"] / max(1, cnt["closest_rays"])
         n_tri = cnt["closest_tri_tests"] / max(1, cnt["closest_rays"])
         b_ray = B_STATE_CLOSEST + n_node * S_NODE[args.traversal] + n_tri * S_TRI
@@ -217,9 +220,9 @@ def main():
                          "kernel": "k_trace_fast<closest>" if args.traversal == 0 else "k_trace4<closest>", "avg_launch_ms": avg_launch_ms, "launches": launches,
                          "bytes_per_ray": b_ray, "node_visits_per_ray": n_node, "tri_tests_per_ray": n_tri,
                          "kernel_rays_per_s": k_rays / (k_ms * 1e-3) if k_ms > 0 else 0.0,
-                         "shadow_kernel_ms": sum(s["trace_shadow_ms"] for s in stats),
-                         "logic_kernel_ms": sum(s["logic_ms"] for s in stats),
-                         "closest_kernel_ms": k_ms},
+                         "closest_kernel_ms_timed_steps": k_ms,
+                         "one_frame_kernel_ms": {"closest": split["trace_closest_ms"], "shadow": split["trace_shadow_ms"],
+                                                 "logic": split["logic_ms"]}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, args)

@@ -80,7 +80,8 @@ typedef struct mirt_options {
   uint32_t sample_begin;    /* rng_mode 1 only: first sample index of this process's spp slice */
   uint32_t sample_count;    /* rng_mode 1 only: samples in the slice; 0 = samples_per_pixel */
   uint32_t glass_int_abs;   /* 1 = reproduce the g++ build's integer abs() in GLASS (bsdf.cuh:213) */
-  uint32_t flags;           /* bit 0 = per-launch event timing into mirt_stats, bit 1 = count node visits / triangle tests,
+  uint32_t flags;           /* bit 0 = per-launch event timing into mirt_stats (bit 3: of the closest-hit launches only),
+                               bit 1 = count node visits / triangle tests,
                                bit 2 = progressive pass (mirt_render_accum, rng_mode 1): add this call's samples
                                [sample_begin, sample_begin + sample_count) to what accum_dev already holds instead of
                                clearing it; mirt_tonemap of the buffer after any pass is the image so far */

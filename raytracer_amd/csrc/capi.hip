@@ -601,6 +601,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   a.mf_queue = s->mf_queue.as<uint32_t>(); a.mf_count = ctrl + CTRL_MF;
 
   const bool profile = stats && (o.flags & 1u);
+  const bool profile_closest = stats && (o.flags & 9u);                  // bit 3: time the closest-hit launches only
   const bool counting = stats && (o.flags & 2u);
   double ms_kind[3] = {0, 0, 0};
   uint32_t n_kind[3] = {0, 0, 0};
@@ -697,7 +698,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
           if (rc) return rc;
           HIPCHK(hipEventRecord(G.join_ev[p][slot], side));
         }
-        rc = run_trace(s, pp.tc, false, o.traversal, profile ? &timed : nullptr, counting, main, pipe_blocks);
+        rc = run_trace(s, pp.tc, false, o.traversal, profile_closest ? &timed : nullptr, counting, main, pipe_blocks);
         if (rc) return rc;
         if (K && !fork) {
           rc = run_trace(s, pp.ts, true, o.traversal, profile ? &timed : nullptr, counting, main, pipe_blocks);
