@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (what the driver runs); gloo = rehearsal of the N > 1 path on a box "
                          "with fewer GPUs than ranks: ranks share the GPUs and the buffers are summed through host memory")
+    ap.add_argument("--split", action="store_true", help="add the per-kernel time split of one extra frame to the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -186,8 +187,11 @@ def main():
         # traversal work per ray (counting build of the same kernels, one untimed reduced-spp frame)
         cnt = scene.render_accum(w, h, accum.data_ptr(), spp=min(4, args.spp), spl=1, batch=args.spp + 1, tol=0.0,
                                  depth=args.depth, **{**opt, "count": True, "sample_count": 0, "sample_begin": 0})
-        # one more untimed frame with events around every launch, for the per-kernel split
-        split = scene.render_accum(w, h, accum.data_ptr(), **kw, **{**opt, "profile": True, "profile_closest": False})
+        # optional: one more untimed frame with events around every launch, for the per-kernel split (not by default, so
+        # that a kernel trace of the default command holds the launches of the warm-up and timed frames only)
+        split = None
+        if args.split:
+            split = scene.render_accum(w, h, accum.data_ptr(), **kw, **{**opt, "profile": True, "profile_closest": False})
         n_node = cnt["closest_node_visits"] / max(1, cnt["closest_rays"])
         n_tri = cnt["closest_tri_tests"] / max(1, cnt["closest_rays"])
         b_ray = B_STATE_CLOSEST + n_node * S_NODE[args.traversal] + n_tri * S_TRI
@@ -221,8 +225,8 @@ def main():
                          "bytes_per_ray": b_ray, "node_visits_per_ray": n_node, "tri_tests_per_ray": n_tri,
                          "kernel_rays_per_s": k_rays / (k_ms * 1e-3) if k_ms > 0 else 0.0,
                          "closest_kernel_ms_timed_steps": k_ms,
-                         "one_frame_kernel_ms": {"closest": split["trace_closest_ms"], "shadow": split["trace_shadow_ms"],
-                                                 "logic": split["logic_ms"]}},
+                         "one_frame_kernel_ms": None if split is None else {
+                             "closest": split["trace_closest_ms"], "shadow": split["trace_shadow_ms"], "logic": split["logic_ms"]}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, args)
