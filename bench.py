@@ -62,13 +62,18 @@ def parse():
     return ap.parse_args()
 
 
-def traffic_per_launch():
+def traffic_per_launch(args, world):
     """HBM bytes per launch of the dominant kernel, from the committed PMC passes of this same command (rocprofv3 cannot
     wrap itself: tools/make_profiles.sh collects FETCH_SIZE / WRITE_SIZE in separate runs, profiles/traffic.json holds the
-    corrected figure).  None when the file is absent."""
+    corrected figure).  None when the file is absent or was collected on another configuration than the one running."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            return json.load(fh)["hbm_bytes_per_launch"]
+            d = json.load(fh)
+        mine = {"workload": args.workload, "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth,
+                "streams": args.streams, "traversal": args.traversal, "n_gpus": world}
+        if d.get("configuration") != mine:
+            return None
+        return d["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -220,7 +225,7 @@ def main():
                        "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
                        "scene_build_s": build_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_per_launch(),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_per_launch(args, world),
                          "kernel": "k_trace_fast<closest>" if args.traversal == 0 else "k_trace4<closest>", "avg_launch_ms": avg_launch_ms, "launches": launches,
                          "bytes_per_ray": b_ray, "node_visits_per_ray": n_node, "tri_tests_per_ray": n_tri,
                          "kernel_rays_per_s": k_rays / (k_ms * 1e-3) if k_ms > 0 else 0.0,
