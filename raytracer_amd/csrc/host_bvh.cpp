@@ -2,14 +2,68 @@
 // See host_bvh.hpp.  Compiled without FMA contraction: every float here must round as the reference's g++ build does.
 #include "host_bvh.hpp"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <limits>
 #include <stdexcept>
+#include <thread>
 
 namespace mirt {
 namespace {
+
+// Both top-down builders hand the two halves of a large range to two threads for the first few levels (the halves are
+// independent: disjoint ranges of `order`, node records drawn from a pre-sized pool).  The trees do not depend on it.
+int fork_levels() {
+  unsigned t = std::thread::hardware_concurrency();
+  if (const char *e = std::getenv("OMP_NUM_THREADS")) {       // the GPU box's CPU share (nproc shows the whole machine there)
+    int v = std::atoi(e);
+    if (v >= 1) t = (unsigned) v;
+  }
+  if (const char *e = std::getenv("MIRT_BUILD_THREADS")) {
+    int v = std::atoi(e);
+    if (v >= 1) t = (unsigned) v;
+  }
+  if (t > 64) t = 64;
+  int d = 0;
+  while ((1u << d) < 2 * t && t > 1) d++;                      // about two tasks per thread
+  return d;
+}
+struct StageClock {                                            // MIRT_BUILD_TIMING=1: stage times on stderr
+  bool on = std::getenv("MIRT_BUILD_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[mirt build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+constexpr uint32_t FORK_MIN = 16384;                           // primitives below which a range is not worth a thread
+
+template<class L, class R>
+void fork_join(bool parallel, L &&left, R &&right) {
+  if (!parallel) {
+    left();
+    right();
+    return;
+  }
+  std::exception_ptr err;
+  std::thread t([&] {
+    try { left(); } catch (...) { err = std::current_exception(); }
+  });
+  try {
+    right();
+  } catch (...) {
+    t.join();
+    throw;
+  }
+  t.join();
+  if (err) std::rethrow_exception(err);
+}
 
 // util/misc.cuh:28-29 on the g++ path: maxf = std::max, minf = std::min (argument order matters for NaN)
 inline float maxf(float a, float b) { return (a < b) ? b : a; }
@@ -32,12 +86,16 @@ struct Builder {
     int32_t l = -1, r = -1;
     uint32_t start = 0, end = 0;
   };
-  std::vector<TNode> tree;
+  std::vector<TNode> tree;               // pool of 2n records; ids are handed out by `next` (flatten() assigns the final order)
+  std::atomic<uint32_t> next{0};
+  int fork_depth = 0;
 
   void prepare(uint32_t n) {
     pbox.resize(n);
     pcent.resize(3 * (size_t) n);
     order.resize(n);
+    tree.resize(2 * (size_t) n);
+    fork_depth = fork_levels();
     for (uint32_t i = 0; i < n; i++) {
       const float *p = pos + 9 * (size_t) i;
       Box b;
@@ -64,7 +122,7 @@ struct Builder {
     }
   }
 
-  int32_t construct(uint32_t start, uint32_t end) {      // bvh.cuh:187-225
+  int32_t construct(uint32_t start, uint32_t end, int depth = 0) {      // bvh.cuh:187-225
     Box bb;
     for (int a = 0; a < 3; a++) {
       bb.lo[a] = std::numeric_limits<float>::infinity();
@@ -77,8 +135,8 @@ struct Builder {
         bb.hi[a] = maxf(bb.hi[a], b.hi[a]);
       }
     }
-    int32_t id = (int32_t) tree.size();
-    tree.emplace_back();
+    const int32_t id = (int32_t) next.fetch_add(1);
+    if ((size_t) id >= tree.size()) throw std::runtime_error("node pool exhausted");
     tree[id].bb = bb;
     if ((int64_t) end - (int64_t) start <= (int64_t) max_leaf) {
       tree[id].start = start;
@@ -119,8 +177,9 @@ struct Builder {
       tree[id].end = end;
       return id;
     }
-    int32_t l = construct(start, middle);
-    int32_t r = construct(middle, end);
+    int32_t l = -1, r = -1;
+    fork_join(depth < fork_depth && end - start >= FORK_MIN, [&] { l = construct(start, middle, depth + 1); },
+              [&] { r = construct(middle, end, depth + 1); });
     tree[id].l = l;
     tree[id].r = r;
     return id;
@@ -246,15 +305,18 @@ void build_reference_bvh2(const float *tri_pos, const uint8_t *prim_type, uint32
   bd.pos = tri_pos;
   bd.ptype = prim_type;
   bd.max_leaf = max_leaf_size;
+  StageClock clk;
   bd.prepare(n);
-  bd.tree.reserve((size_t) n);
+  clk.lap("reference: boxes, centroids");
   int32_t root = bd.construct(0, n);
+  clk.lap("reference: construct");
   out.nodes2.clear();
-  out.nodes2.reserve(bd.tree.size());
+  out.nodes2.reserve(bd.next.load());
   out.flat_to_orig.assign(n, 0);
   uint32_t prim_start = 0;
   bd.flatten(root, out, prim_start);
   out.depth2 = bd.depth_of(root, 0);
+  clk.lap("reference: flatten");
 }
 
 void collapse_to_wide(HostBVH &bvh) {
@@ -280,8 +342,10 @@ struct SahBuilder {
   std::vector<Box> pbox;
   std::vector<float> cent;
   std::vector<uint32_t> order;
-  std::vector<Node2> &out;
-  std::vector<uint32_t> &perm;
+  std::vector<Node2> &out;                // pool of 2n records, ids from `next`
+  std::vector<uint32_t> &perm;            // = order when the build is done (a leaf's primitives are its range of `order`)
+  std::atomic<uint32_t> next{0};
+  int fork_depth = 0;
   uint32_t max_leaf;
   static constexpr int BINS = 16;
 
@@ -310,6 +374,8 @@ struct SahBuilder {
     pbox.resize(n);
     cent.resize(3 * (size_t) n);
     order.resize(n);
+    out.resize(2 * (size_t) n);
+    fork_depth = fork_levels();
     for (uint32_t i = 0; i < n; i++) {
       const float *p = pos + 9 * (size_t) i;
       Box b = empty();
@@ -332,7 +398,7 @@ struct SahBuilder {
     }
   }
 
-  uint32_t build(uint32_t s, uint32_t e) {
+  uint32_t build(uint32_t s, uint32_t e, int depth = 0) {
     Box bb = empty(), cb = empty();
     for (uint32_t i = s; i < e; i++) {
       grow(bb, pbox[order[i]]);
@@ -342,14 +408,13 @@ struct SahBuilder {
         cb.hi[k] = std::fmax(cb.hi[k], c);
       }
     }
-    uint32_t id = (uint32_t) out.size();
-    out.emplace_back();
+    const uint32_t id = next.fetch_add(1);
+    if ((size_t) id >= out.size()) throw std::runtime_error("node pool exhausted");
     for (int k = 0; k < 3; k++) { out[id].minp[k] = bb.lo[k]; out[id].maxp[k] = bb.hi[k]; }
     const uint32_t n = e - s;
     if (n <= max_leaf) {
       out[id].w0 = 0x80000000u | n;
-      out[id].w1 = (uint32_t) perm.size();
-      for (uint32_t i = s; i < e; i++) perm.push_back(order[i]);
+      out[id].w1 = s;
       return id;
     }
     // binned SAH over the three axes
@@ -398,8 +463,8 @@ struct SahBuilder {
       mid = i;
       if (mid == s || mid == e) mid = s + n / 2;
     }
-    uint32_t l = build(s, mid);
-    uint32_t r = build(mid, e);
+    uint32_t l = 0, r = 0;
+    fork_join(depth < fork_depth && n >= FORK_MIN, [&] { l = build(s, mid, depth + 1); }, [&] { r = build(mid, e, depth + 1); });
     out[id].w0 = l;
     out[id].w1 = r;
     return id;
@@ -512,9 +577,7 @@ struct Collapser8 {
 
 void build_fast_tree(const float *tri_pos_flat, const uint8_t *prim_type_flat, uint32_t n, HostBVH &bvh) {
   std::vector<Node2> n2;
-  n2.reserve((size_t) n);
   bvh.fast_to_flat.clear();
-  bvh.fast_to_flat.reserve(n);
   SahBuilder sb(n2, bvh.fast_to_flat);
   sb.pos = tri_pos_flat;
   sb.ptype = prim_type_flat;
@@ -523,10 +586,15 @@ void build_fast_tree(const float *tri_pos_flat, const uint8_t *prim_type_flat, u
     int v = std::atoi(e);
     if (v >= 1 && v <= (int) LEAF_MAX) sb.max_leaf = (uint32_t) v;
   }
+  StageClock clk;
   sb.prepare(n);
+  clk.lap("own tree: boxes, centroids");
   sb.build(0, n);
+  clk.lap("own tree: binned SAH");
+  bvh.fast_to_flat = sb.order;
   Collapser8 c8(n2);
   c8.build(0, 0);
+  clk.lap("own tree: fold to 8-wide");
   bvh.depth8 = c8.max_depth;
   bvh.nodes8q.resize(c8.out.size() * (sizeof(Node8Q) / 4));
   memcpy(bvh.nodes8q.data(), c8.out.data(), c8.out.size() * sizeof(Node8Q));
