@@ -1,6 +1,6 @@
 // Command-line renderer written against the reference's host API (the call sequence of the reference's apps/app.cu:24-30:
 // ctor -> set_camera -> resize -> set_scene -> raytrace -> save_to_file), running on libmirt.so.
-//   render out.bmp [--obj file.obj] [--w 640 --h 360 --spp 16 --depth 8] [--rng 0|1]
+//   render out.bmp [--obj file.obj] [--w 640 --h 360 --spp 16 --depth 8] [--rng 0|1] [--device-build]
 // Without --obj it builds the reference's Generator::room plus a few triangles, so it runs with no assets.
 #include <cstdlib>
 #include <cstring>
@@ -10,7 +10,7 @@
 
 int main(int argc, char **argv) {
   std::string out = "out.bmp", obj;
-  uint w = 640, h = 360, spp = 16, depth = 8, rng = 0;
+  uint w = 640, h = 360, spp = 16, depth = 8, rng = 0, device_build = 0;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     auto next = [&]() { return i + 1 < argc ? argv[++i] : (char *) "0"; };
@@ -20,6 +20,7 @@ int main(int argc, char **argv) {
     else if (a == "--spp") spp = (uint) atoi(next());
     else if (a == "--depth") depth = (uint) atoi(next());
     else if (a == "--rng") rng = (uint) atoi(next());
+    else if (a == "--device-build") device_build = 1;
     else out = a;
   }
   std::vector<Primitive *> prims;
@@ -37,6 +38,7 @@ int main(int argc, char **argv) {
                                     SceneLightFactory::create_point({1.5f, 1.5f, 1.5f}, {1.5f, 2.5f, -1.5f})};
   PathTracer tracer({spp, 1, spp + 1, 0.05f, depth, 4});
   tracer.options.rng_mode = rng;
+  tracer.build_options.own_tree_builder = device_build;
   tracer.set_camera({0, 1.5f, -1.95f}, {0, 1.2f, 0}, {0, 1, 0}, 70, 70.f * h / w, 0, INFINITY);
   tracer.resize(w, h);
   tracer.set_scene(prims, lights);

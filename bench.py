@@ -57,6 +57,8 @@ def parse():
                     help="nccl = RCCL, one GPU per rank (what the driver runs); gloo = rehearsal of the N > 1 path on a box "
                          "with fewer GPUs than ranks: ranks share the GPUs and the buffers are summed through host memory")
     ap.add_argument("--split", action="store_true", help="add the per-kernel time split of one extra frame to the roofline object")
+    ap.add_argument("--builder", default=None, choices=["host", "device"],
+                    help="who builds the ordered traversal's own tree (default: the library's, host binned SAH)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -134,8 +136,9 @@ def main():
     sd = scenes.WORKLOADS[args.workload]()
     sd.camera = sd.camera.for_aspect(args.width, args.height)
     t0 = time.time()
-    scene = capi.Scene(sd)
+    scene = capi.Scene(sd, builder=args.builder)
     build_s = time.time() - t0
+    build_ms = {k: round(v, 2) for k, v in scene.build_times().items()}
     w, h = args.width, args.height
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
 
@@ -223,7 +226,7 @@ def main():
                                    f"{len(sd.lights)} light{'s' if len(sd.lights) != 1 else ''}, rng {'counter' if opt['rng_mode'] else 'xorshift'}, "
                                    f"traversal {args.traversal}, {opt['streams']} sample streams",
                        "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
-                       "scene_build_s": build_s},
+                       "scene_build_s": build_s, "builder": args.builder or "host", "build_ms": build_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_per_launch(args, world),
                          "kernel": "k_trace_fast<closest>" if args.traversal == 0 else "k_trace4<closest>", "avg_launch_ms": avg_launch_ms, "launches": launches,

@@ -137,7 +137,32 @@ int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t
 int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, const uint8_t *prim_type,
                             uint32_t n_prims, const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights,
                             uint32_t n_lights, uint32_t leaf_size, mirt_scene **out);
+
+/* Scene build options.  No counterpart in the reference, whose builder runs on the host only (bvh.cuh:177-225): the
+ * reference's BVH2 (flat primitive order, the tree of traversals 1 and 2 and of the near-tie replay) is always rebuilt on the
+ * host bit for bit; the option selects who builds the ordered traversal's OWN tree, which is free in its topology. */
+typedef struct mirt_build_options {
+  uint32_t own_tree_builder;    /* 0: host, binned SAH (default; best traversal) | 1: device: Morton order, binary radix
+                                 * tree, bottom-up boxes, fold to 8-wide (raytracer_amd/csrc/build.hip; for scenes that
+                                 * are rebuilt every frame, the reference app's 80-frame loop apps/app.cu:24-30) */
+  uint32_t reserved[7];
+} mirt_build_options;
+
+/* mirt_scene_create_prims with build options (NULL: defaults, or MIRT_BUILDER=device from the environment). */
+int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, const uint8_t *prim_type,
+                           uint32_t n_prims, const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights,
+                           uint32_t n_lights, uint32_t leaf_size, const mirt_build_options *build, mirt_scene **out);
 void mirt_scene_destroy(mirt_scene *scene);
+
+/* ms[8]: reference BVH2 on the host (replaces the timing print of bvh.cuh:177-185), its fold to 4-wide, the own tree in
+ * total, then the device builder's stages (upload + keys + sort | radix tree + boxes | fold | gather; 0 for the host
+ * builder), uploads. */
+int mirt_scene_build_times(const mirt_scene *scene, float ms[8]);
+
+/* The ordered traversal's own tree as it sits on the device, for structure tests.  counts[4] = 8-wide nodes (0: the scene
+ * has no such tree), levels below the root, primitives, builder used; nodes8q_out: 24 dwords per node; prims_out: 12 dwords
+ * per primitive in tree order (word 9 = flat index).  Either may be NULL.  No reference counterpart. */
+int mirt_scene_own_tree(const mirt_scene *scene, uint32_t counts[4], uint32_t *nodes8q_out, uint32_t *prims_out);
 
 /* info[0..7]: bvh2 nodes, bvh2 depth (BVHAccel::get_max_depth, bvh.cuh:297), wide nodes, wide depth, n_tris, n_mats,
  * n_lights, device bytes / 1024. */

@@ -284,6 +284,8 @@ public:
   std::shared_ptr<Camera> camera;
   std::shared_ptr<SampleBuffer> sample_buffer;
   mirt_options options;                                      // extension: zero = reference behaviour
+  mirt_build_options build_options{};                        // extension: zero = host builders only (own_tree_builder = 1:
+                                                             // the traversal's own tree is built on the GPU, for frame loops)
   mirt_stats stats;
 
   explicit PathTracer(Parameters p = default_parameters, int device = 0) : parameters(p), camera(nullptr) {
@@ -373,9 +375,9 @@ private:
     }
     std::vector<mirt_light> ls;
     for (const SceneLight &l: lights) ls.push_back(l.rec);
-    if (mirt_scene_create_prims(pos.data(), nrm.data(), mat.data(), ptype.data(), (uint32_t) mat.size(), mats.data(),
-                                (uint32_t) mats.size(), ls.data(), (uint32_t) ls.size(), parameters.bvh_node_size,
-                                &scene_) != MIRT_OK) {
+    if (mirt_scene_create_opts(pos.data(), nrm.data(), mat.data(), ptype.data(), (uint32_t) mat.size(), mats.data(),
+                               (uint32_t) mats.size(), ls.data(), (uint32_t) ls.size(), parameters.bvh_node_size,
+                               &build_options, &scene_) != MIRT_OK) {
       std::printf("%s\n", mirt_last_error());
       return false;
     }

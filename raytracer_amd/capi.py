@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MIRT_LIB") or os.path.join(_HERE, "libmirt.so")   # M
 
 SYMBOLS = [
     "mirt_init", "mirt_shutdown", "mirt_last_error", "mirt_version", "mirt_scene_create", "mirt_scene_create_prims",
-    "mirt_scene_destroy",
+    "mirt_scene_create_opts", "mirt_scene_destroy", "mirt_scene_build_times", "mirt_scene_own_tree",
     "mirt_scene_info", "mirt_scene_bvh2", "mirt_camera_look_at", "mirt_render", "mirt_render_accum", "mirt_tonemap",
     "mirt_primary_hits", "mirt_trace", "mirt_save_bmp", "mirt_tonemap_host", "mirt_bvh_build_host",
     "mirt_bvh_build_host_prims",
@@ -49,6 +49,10 @@ class Options(C.Structure):
                 ("tile_world", C.c_uint32), ("sample_begin", C.c_uint32), ("sample_count", C.c_uint32),
                 ("glass_int_abs", C.c_uint32), ("flags", C.c_uint32), ("streams", C.c_uint32),
                 ("reserved", C.c_uint32 * 6)]
+
+
+class BuildOptions(C.Structure):
+    _fields_ = [("own_tree_builder", C.c_uint32), ("reserved", C.c_uint32 * 7)]
 
 
 class Stats(C.Structure):
@@ -146,14 +150,21 @@ def light_records(lights16):
 class Scene:
     """Owns a mirt_scene handle.  Mirrors what PathTracer::set_scene + the BVH part of raytrace() do."""
 
-    def __init__(self, sc, leaf_size=4):
+    def __init__(self, sc, leaf_size=4, builder=None):
+        """builder: None = library default (or MIRT_BUILDER), "host" / "device" = mirt_build_options.own_tree_builder."""
         lib = load()
         self.n = sc.n
         self.mats = bsdf_records(sc.mats)
         self.lights = light_records(sc.lights)
         h = C.c_void_p()
         ptype = getattr(sc, "ptype", None)
-        if ptype is None:
+        if builder is not None:
+            bo = BuildOptions()
+            bo.own_tree_builder = {"host": 0, "device": 1}[builder]
+            _chk(lib.mirt_scene_create_opts(_p(sc.pos), _p(sc.nrm), _p(sc.mat), _p(ptype), C.c_uint32(sc.n), _p(self.mats),
+                                            C.c_uint32(len(self.mats)), _p(self.lights) if len(self.lights) else None,
+                                            C.c_uint32(len(self.lights)), C.c_uint32(leaf_size), C.byref(bo), C.byref(h)))
+        elif ptype is None:
             _chk(lib.mirt_scene_create(_p(sc.pos), _p(sc.nrm), _p(sc.mat), C.c_uint32(sc.n), _p(self.mats),
                                        C.c_uint32(len(self.mats)), _p(self.lights) if len(self.lights) else None,
                                        C.c_uint32(len(self.lights)), C.c_uint32(leaf_size), C.byref(h)))
@@ -182,6 +193,23 @@ class Scene:
         _chk(load().mirt_scene_info(self.h, a))
         keys = ["bvh2_nodes", "bvh2_depth", "wide_nodes", "wide_depth", "n_tris", "n_mats", "n_lights", "device_kib"]
         return dict(zip(keys, list(a)))
+
+    def build_times(self):
+        a = (C.c_float * 8)()
+        _chk(load().mirt_scene_build_times(self.h, a))
+        keys = ["reference_bvh2_ms", "fold4_ms", "own_tree_ms", "dev_sort_ms", "dev_tree_ms", "dev_fold_ms", "dev_gather_ms",
+                "upload_ms"]
+        return dict(zip(keys, [float(x) for x in a]))
+
+    def own_tree(self):
+        """(counts dict, nodes8q (N, 24) uint32, prims (n, 12) uint32) as they sit on the device."""
+        c = (C.c_uint32 * 4)()
+        _chk(load().mirt_scene_own_tree(self.h, c, None, None))
+        nodes = np.zeros((c[0], 24), np.uint32)
+        prims = np.zeros((c[2], 12), np.uint32)
+        if c[0]:
+            _chk(load().mirt_scene_own_tree(self.h, c, _p(nodes), _p(prims)))
+        return {"nodes": c[0], "depth": c[1], "prims": c[2], "builder": c[3]}, nodes, prims
 
     def bvh2(self):
         n_nodes = self.info()["bvh2_nodes"]

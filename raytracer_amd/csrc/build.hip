@@ -1,0 +1,516 @@
+// Device build of the ordered traversal's own tree (the reference builds on the host only,
+// bvh/bvh.cuh:177-290).  The ordered traversal accepts ANY tree whose boxes contain their primitives (DESIGN.md 4:
+// exact primitive tests, near-ties replayed on the reference's tree), so this builder is free in its topology:
+//
+//   boxes + centroids -> 63-bit Morton keys -> radix sort (rocPRIM) -> binary radix tree (Karras 2012: one thread per
+//   inner node finds its key range and split) -> boxes bottom-up (the second thread to arrive at a node merges its
+//   children) -> fold to 8-wide quantised nodes level by level (largest-area child opened first; a subtree of at most
+//   `max_leaf` primitives, contiguous in sorted order, becomes a leaf) -> primitive records gathered into tree order.
+//
+// The 96-byte node and its conservative 8-bit planes are exactly host_bvh.cpp's (Collapser8); the kernels here redo that
+// arithmetic in double, including the containment checks.
+#include <cstring>
+#include <string>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "device_build.hpp"
+#include "host_bvh.hpp"
+
+namespace mirt {
+namespace {
+
+constexpr uint32_t LEAF_BIT = 0x80000000u;
+constexpr int BLOCK = 256;
+
+__device__ __forceinline__ uint32_t f2o(float f) {          // float -> unsigned with the same order
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float o2f(uint32_t o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+struct Boxes {
+  float4 *lo, *hi;                                          // per primitive, flat order
+};
+
+// scene[0..2] = min of the centroids, scene[3..5] = max (ordered-uint form); flags bit 0: a non-finite coordinate
+__global__ void __launch_bounds__(BLOCK) k_prim_boxes(const float *__restrict__ pos, const uint8_t *__restrict__ ptype,
+                                                      uint32_t n, Boxes bx, uint32_t *scene, uint32_t *flags) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+  bool bad = false;
+  if (i < n) {
+    const float *p = pos + 9 * (size_t) i;
+    if (ptype && ptype[i] == 1) {                           // sphere: one ulp of room (as SahBuilder::prepare)
+      for (int k = 0; k < 3; k++) {
+        lo[k] = nextafterf(p[k] - p[3], -INFINITY);
+        hi[k] = nextafterf(p[k] + p[3], INFINITY);
+      }
+    } else {
+      for (int v = 0; v < 3; v++)
+        for (int k = 0; k < 3; k++) {
+          lo[k] = fminf(lo[k], p[3 * v + k]);
+          hi[k] = fmaxf(hi[k], p[3 * v + k]);
+          bad = bad || !isfinite(p[3 * v + k]);
+        }
+    }
+    for (int k = 0; k < 3; k++) {
+      bad = bad || !isfinite(lo[k]) || !isfinite(hi[k]);
+      const float c = 0.5f * (lo[k] + hi[k]);
+      bad = bad || !isfinite(c);
+      cmin[k] = c;
+      cmax[k] = c;
+    }
+    bx.lo[i] = make_float4(lo[0], lo[1], lo[2], 0.f);
+    bx.hi[i] = make_float4(hi[0], hi[1], hi[2], 0.f);
+  }
+  // workgroup reduction of the centroid bounds: one atomic per component and workgroup
+  __shared__ float red[6][BLOCK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < 3; k++) {
+    float a = cmin[k], b = cmax[k];
+    for (int o = 32; o > 0; o >>= 1) {
+      a = fminf(a, __shfl_xor(a, o));
+      b = fmaxf(b, __shfl_xor(b, o));
+    }
+    if (lane == 0) {
+      red[k][wave] = a;
+      red[3 + k][wave] = b;
+    }
+  }
+  if (__any(bad) && lane == 0) atomicOr(flags, 1u);
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    float v = red[k][0];
+    for (int w = 1; w < BLOCK / 64; w++) v = (k < 3) ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
+    if (isfinite(v)) {
+      if (k < 3) atomicMin(&scene[k], f2o(v));
+      else atomicMax(&scene[k], f2o(v));
+    }
+  }
+}
+
+__device__ __forceinline__ uint64_t spread3(uint32_t a) {   // 21 bits -> every third bit
+  uint64_t x = a & 0x1FFFFFu;
+  x = (x | x << 32) & 0x001F00000000FFFFull;
+  x = (x | x << 16) & 0x001F0000FF0000FFull;
+  x = (x | x << 8) & 0x100F00F00F00F00Full;
+  x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_morton(Boxes bx, uint32_t n, const uint32_t *__restrict__ scene,
+                                                  uint64_t *keys, uint32_t *vals) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const float4 lo = bx.lo[i], hi = bx.hi[i];
+  const float c[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+  uint32_t q[3];
+  for (int k = 0; k < 3; k++) {
+    const float mn = o2f(scene[k]), mx = o2f(scene[3 + k]);
+    const double ext = (double) mx - (double) mn;
+    double t = ext > 0 ? ((double) c[k] - (double) mn) / ext * 2097152.0 : 0.0;
+    t = t < 0 ? 0 : (t > 2097151.0 ? 2097151.0 : t);
+    q[k] = (uint32_t) t;
+  }
+  keys[i] = spread3(q[0]) << 2 | spread3(q[1]) << 1 | spread3(q[2]);
+  vals[i] = i;
+}
+
+// ---- binary radix tree over the sorted keys (Karras, "Maximizing parallelism in the construction of BVHs, octrees and
+// k-d trees", HPG 2012, section 4).  Inner node i, leaves 0..n-1; child references carry LEAF_BIT for leaves.
+struct Radix {
+  const uint64_t *keys;
+  uint32_t n;
+  uint2 *child;                                             // per inner node: (left, right)
+  uint2 *range;                                             // per inner node: (first, last) sorted positions
+  uint32_t *parent_inner, *parent_leaf;
+};
+
+__device__ __forceinline__ int delta(const Radix &r, int i, int j) {
+  if (j < 0 || j >= (int) r.n) return -1;
+  const uint64_t a = r.keys[i], b = r.keys[j];
+  if (a == b) return 64 + __clz((uint32_t) i ^ (uint32_t) j);
+  return __clzll((long long) (a ^ b));
+}
+
+__global__ void __launch_bounds__(BLOCK) k_radix_tree(Radix r) {
+  const int i = (int) (blockIdx.x * BLOCK + threadIdx.x);
+  if (i >= (int) r.n - 1) return;
+  const int d = (delta(r, i, i + 1) - delta(r, i, i - 1)) < 0 ? -1 : 1;
+  const int dmin = delta(r, i, i - d);
+  int lmax = 2;
+  while (delta(r, i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (delta(r, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(r, i, j);
+  int s = 0, t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (delta(r, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + (d < 0 ? d : 0);
+  const int first = i < j ? i : j, last = i < j ? j : i;
+  const uint32_t left = (first == gamma) ? (LEAF_BIT | (uint32_t) gamma) : (uint32_t) gamma;
+  const uint32_t right = (last == gamma + 1) ? (LEAF_BIT | (uint32_t) (gamma + 1)) : (uint32_t) (gamma + 1);
+  r.child[i] = make_uint2(left, right);
+  r.range[i] = make_uint2((uint32_t) first, (uint32_t) last);
+  if (left & LEAF_BIT) r.parent_leaf[gamma] = (uint32_t) i;
+  else r.parent_inner[gamma] = (uint32_t) i;
+  if (right & LEAF_BIT) r.parent_leaf[gamma + 1] = (uint32_t) i;
+  else r.parent_inner[gamma + 1] = (uint32_t) i;
+  if (i == 0) r.parent_inner[0] = 0xFFFFFFFFu;
+}
+
+// ---- boxes bottom-up.  One thread per leaf climbs; at every inner node the first arrival stops, the second (which by
+// then can see both children's boxes: acquire/release on the arrival counter) merges them and climbs on.
+struct Refit {
+  uint32_t n;
+  const uint32_t *sorted;                                   // sorted position -> flat primitive
+  Boxes prim;
+  const uint2 *child;
+  const uint32_t *parent_inner, *parent_leaf;
+  uint32_t *arrived;
+  float4 *nlo, *nhi;                                        // per inner node
+};
+
+__device__ __forceinline__ void ref_box(const Refit &r, uint32_t ref, float4 &lo, float4 &hi) {
+  if (ref & LEAF_BIT) {
+    const uint32_t p = r.sorted[ref & ~LEAF_BIT];
+    lo = r.prim.lo[p];
+    hi = r.prim.hi[p];
+  } else {
+    lo = r.nlo[ref];
+    hi = r.nhi[ref];
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_refit(Refit r) {
+  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= r.n || r.n < 2) return;
+  uint32_t cur = r.parent_leaf[j];
+  while (cur != 0xFFFFFFFFu) {
+    const uint32_t before = __hip_atomic_fetch_add(&r.arrived[cur], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == 0) return;
+    const uint2 c = r.child[cur];
+    float4 alo, ahi, blo, bhi;
+    ref_box(r, c.x, alo, ahi);
+    ref_box(r, c.y, blo, bhi);
+    r.nlo[cur] = make_float4(fminf(alo.x, blo.x), fminf(alo.y, blo.y), fminf(alo.z, blo.z), 0.f);
+    r.nhi[cur] = make_float4(fmaxf(ahi.x, bhi.x), fmaxf(ahi.y, bhi.y), fmaxf(ahi.z, bhi.z), 0.f);
+    cur = r.parent_inner[cur];
+  }
+}
+
+// ---- fold to 8-wide quantised nodes, one level per launch.  Entry e of the level's queue is the binary-tree reference
+// that becomes wide node base + e; inner children are appended to the next level's queue, whose position is their index.
+struct Fold {
+  uint32_t n, max_leaf;
+  const uint32_t *sorted;
+  Boxes prim;
+  const uint2 *child, *range;
+  const float4 *nlo, *nhi;
+  const uint32_t *queue;
+  uint32_t count, base;
+  uint32_t *next_queue, *next_count;                        // next_count[0]: entries, next_count[1]: error flags
+  uint32_t next_base;
+  uint32_t *nodes;                                          // 24 words per wide node
+};
+
+__device__ __forceinline__ void fold_box(const Fold &f, uint32_t ref, float lo[3], float hi[3]) {
+  float4 a, b;
+  if (ref & LEAF_BIT) {
+    const uint32_t p = f.sorted[ref & ~LEAF_BIT];
+    a = f.prim.lo[p];
+    b = f.prim.hi[p];
+  } else {
+    a = f.nlo[ref];
+    b = f.nhi[ref];
+  }
+  lo[0] = a.x; lo[1] = a.y; lo[2] = a.z;
+  hi[0] = b.x; hi[1] = b.y; hi[2] = b.z;
+}
+__device__ __forceinline__ uint32_t fold_count(const Fold &f, uint32_t ref) {
+  if (ref & LEAF_BIT) return 1;
+  const uint2 r = f.range[ref];
+  return r.y - r.x + 1;
+}
+__device__ __forceinline__ uint32_t fold_first(const Fold &f, uint32_t ref) {
+  return (ref & LEAF_BIT) ? (ref & ~LEAF_BIT) : f.range[ref].x;
+}
+
+__global__ void __launch_bounds__(64) k_fold_level(Fold f) {
+  const uint32_t e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= f.count) return;
+  const uint32_t root = f.queue[e];
+  uint32_t kids[8];
+  float area[8];                                            // < 0: a leaf (not to be opened)
+  int nk = 0;
+  auto add = [&](int k, uint32_t ref) {
+    kids[k] = ref;
+    if (fold_count(f, ref) <= f.max_leaf) {
+      area[k] = -1.f;
+    } else {
+      float lo[3], hi[3];
+      fold_box(f, ref, lo, hi);
+      const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+      area[k] = dx * dy + dy * dz + dz * dx;
+    }
+  };
+  if (fold_count(f, root) <= f.max_leaf) {
+    add(nk++, root);                                        // a scene that is one leaf
+  } else {
+    const uint2 c = f.child[root];
+    add(nk++, c.x);
+    add(nk++, c.y);
+    while (nk < 8) {
+      int best = -1;
+      float best_a = -1.f;
+      for (int k = 0; k < nk; k++)
+        if (area[k] >= 0.f && !(area[k] <= best_a)) { best_a = area[k]; best = k; }
+      if (best < 0) break;
+      const uint2 c2 = f.child[kids[best]];
+      add(best, c2.x);
+      add(nk++, c2.y);
+    }
+  }
+  float rlo[3], rhi[3];
+  fold_box(f, root, rlo, rhi);
+  uint32_t words[24];
+  for (int k = 0; k < 24; k++) words[k] = 0;
+  uint32_t err = 0;
+  int eb[3];
+  uint8_t qlo[3][8], qhi[3][8];
+  for (int a = 0; a < 3; a++)
+    for (int k = 0; k < 8; k++) qlo[a][k] = qhi[a][k] = 0;
+  for (int a = 0; a < 3; a++) {
+    words[a] = __float_as_uint(rlo[a]);
+    const double p = (double) rlo[a];
+    const double ext = (double) rhi[a] - p;
+    int ex = -126;
+    if (ext > 0) {
+      int fe;
+      (void) frexp(ext / 255.0, &fe);                       // ext / 255 = m * 2^fe, m in [0.5, 1)  =>  2^fe >= ext / 255
+      ex = fe;
+    }
+    if (ex < -126) ex = -126;
+    if (ex > 127) { err |= 2; ex = 127; }
+    eb[a] = ex + 127;
+    double step = ldexp(1.0, ex);
+    for (int tries = 0; tries < 4; tries++) {               // (a second pass only when rounding pushes a plane past 255)
+      bool fits = true;
+      for (int k = 0; k < nk && fits; k++) {
+        float clo[3], chi[3];
+        fold_box(f, kids[k], clo, chi);
+        const double cmin = (double) clo[a], cmax = (double) chi[a];
+        double lo = floor((cmin - p) / step), hi = ceil((cmax - p) / step);
+        if (lo < 0) lo = 0;
+        while (lo > 0 && p + lo * step > cmin) lo -= 1;
+        while (p + hi * step < cmax && hi <= 255) hi += 1;
+        if (hi > 255 || p + lo * step > cmin) { fits = false; break; }
+        qlo[a][k] = (uint8_t) lo;
+        qhi[a][k] = (uint8_t) hi;
+      }
+      if (fits) break;
+      if (tries == 3 || ++eb[a] > 254) { err |= 2; break; }
+      step *= 2.0;
+    }
+  }
+  words[3] = (uint32_t) eb[0] | ((uint32_t) eb[1] << 8) | ((uint32_t) eb[2] << 16);
+  for (int k = 0; k < 8; k++) words[4 + k] = CHILD_EMPTY;
+  for (int k = 0; k < nk; k++) {
+    const uint32_t cnt = fold_count(f, kids[k]);
+    if (cnt <= f.max_leaf) {
+      words[4 + k] = CHILD_LEAF | (cnt << LEAF_COUNT_SHIFT) | fold_first(f, kids[k]);
+    } else {
+      const uint32_t pos = atomicAdd(&f.next_count[0], 1u);
+      f.next_queue[pos] = kids[k];
+      words[4 + k] = f.next_base + pos;
+    }
+  }
+  for (int a = 0; a < 3; a++)
+    for (int k = 0; k < 8; k++) {
+      words[12 + 2 * a + (k >> 2)] |= (uint32_t) qlo[a][k] << (8 * (k & 3));
+      words[18 + 2 * a + (k >> 2)] |= (uint32_t) qhi[a][k] << (8 * (k & 3));
+    }
+  uint4 *out = (uint4 *) (f.nodes + (size_t) (f.base + e) * 24);
+  for (int k = 0; k < 6; k++) out[k] = make_uint4(words[4 * k], words[4 * k + 1], words[4 * k + 2], words[4 * k + 3]);
+  if (err) atomicOr(&f.next_count[1], err);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_gather_records(const uint4 *__restrict__ tris, const uint32_t *__restrict__ sorted,
+                                                          uint32_t n, uint4 *__restrict__ out) {
+  const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t >= 3 * n) return;
+  const uint32_t j = t / 3, q = t % 3;
+  out[t] = tris[(size_t) sorted[j] * 3 + q];
+}
+
+struct Scratch {                                            // frees what the build allocated and does not hand over
+  std::vector<void *> ptrs;
+  ~Scratch() { for (void *p: ptrs) (void) hipFree(p); }
+  template<class T> hipError_t get(T **out, size_t count) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, count * sizeof(T) + 16);
+    if (e == hipSuccess) ptrs.push_back(p);
+    *out = (T *) p;
+    return e;
+  }
+};
+
+}  // namespace
+
+#define BCHK(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) { res.error = std::string(#expr) + ": " + hipGetErrorString(e_); return -1; } \
+  } while (0)
+
+int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat_host, const void *tris_dev, uint32_t n,
+                           uint32_t max_leaf, hipStream_t stream, DeviceTree &res) {
+  res = DeviceTree();
+  if (n < 2) { res.error = "fewer than two primitives"; return 1; }
+  if (max_leaf < 1 || max_leaf > LEAF_MAX) max_leaf = 3;
+  Scratch sc;
+  float *d_pos = nullptr;
+  uint8_t *d_type = nullptr;
+  Boxes bx{};
+  uint32_t *d_scene = nullptr;                               // 6 bounds + flags + pad
+  uint64_t *keys_a = nullptr, *keys_b = nullptr;
+  uint32_t *vals_a = nullptr, *vals_b = nullptr;
+  BCHK(sc.get(&d_pos, (size_t) n * 9));
+  if (ptype_flat_host) BCHK(sc.get(&d_type, n));
+  BCHK(sc.get(&bx.lo, n));
+  BCHK(sc.get(&bx.hi, n));
+  BCHK(sc.get(&d_scene, 8));
+  BCHK(sc.get(&keys_a, n));
+  BCHK(sc.get(&keys_b, n));
+  BCHK(sc.get(&vals_a, n));
+  BCHK(sc.get(&vals_b, n));
+  hipEvent_t ev[5];
+  for (auto &e: ev) BCHK(hipEventCreate(&e));
+  struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 5; i++) (void) hipEventDestroy(e[i]); } } guard{ev};
+
+  BCHK(hipMemcpyAsync(d_pos, pos_flat_host, (size_t) n * 9 * sizeof(float), hipMemcpyHostToDevice, stream));
+  if (d_type) BCHK(hipMemcpyAsync(d_type, ptype_flat_host, n, hipMemcpyHostToDevice, stream));
+  const uint32_t init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
+  BCHK(hipMemcpyAsync(d_scene, init, sizeof init, hipMemcpyHostToDevice, stream));
+  BCHK(hipEventRecord(ev[0], stream));
+  const uint32_t nb = (n + BLOCK - 1) / BLOCK;
+  hipLaunchKernelGGL(k_prim_boxes, dim3(nb), dim3(BLOCK), 0, stream, d_pos, d_type, n, bx, d_scene, d_scene + 6);
+  hipLaunchKernelGGL(k_morton, dim3(nb), dim3(BLOCK), 0, stream, bx, n, d_scene, keys_a, vals_a);
+  BCHK(hipGetLastError());
+  size_t tmp_bytes = 0;
+  BCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, vals_b, n, 0, 63, stream));
+  char *d_tmp = nullptr;
+  BCHK(sc.get(&d_tmp, tmp_bytes));
+  BCHK(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, n, 0, 63, stream));
+  BCHK(hipEventRecord(ev[1], stream));
+
+  Radix rt{};
+  rt.keys = keys_b;
+  rt.n = n;
+  BCHK(sc.get(&rt.child, n));
+  BCHK(sc.get(&rt.range, n));
+  BCHK(sc.get(&rt.parent_inner, n));
+  BCHK(sc.get(&rt.parent_leaf, n));
+  hipLaunchKernelGGL(k_radix_tree, dim3(nb), dim3(BLOCK), 0, stream, rt);
+  Refit rf{};
+  rf.n = n;
+  rf.sorted = vals_b;
+  rf.prim = bx;
+  rf.child = rt.child;
+  rf.parent_inner = rt.parent_inner;
+  rf.parent_leaf = rt.parent_leaf;
+  BCHK(sc.get(&rf.arrived, n));
+  BCHK(sc.get(&rf.nlo, n));
+  BCHK(sc.get(&rf.nhi, n));
+  BCHK(hipMemsetAsync(rf.arrived, 0, (size_t) n * 4, stream));
+  hipLaunchKernelGGL(k_refit, dim3(nb), dim3(BLOCK), 0, stream, rf);
+  BCHK(hipGetLastError());
+  BCHK(hipEventRecord(ev[2], stream));
+
+  // fold, level by level; at most n - 1 wide nodes (every one but a lone root has two or more children)
+  uint32_t *d_nodes = nullptr, *queue_a = nullptr, *queue_b = nullptr, *d_next = nullptr;
+  BCHK(sc.get(&d_nodes, (size_t) n * 24));
+  BCHK(sc.get(&queue_a, n));
+  BCHK(sc.get(&queue_b, n));
+  BCHK(sc.get(&d_next, 2));
+  uint32_t h_flags = 0;
+  BCHK(hipMemcpyAsync(&h_flags, d_scene + 6, 4, hipMemcpyDeviceToHost, stream));
+  const uint32_t root_ref = 0;
+  BCHK(hipMemcpyAsync(queue_a, &root_ref, 4, hipMemcpyHostToDevice, stream));
+  BCHK(hipStreamSynchronize(stream));
+  if (h_flags & 1) { res.error = "non-finite vertex: no quantised tree"; return 1; }
+  Fold fd{};
+  fd.n = n;
+  fd.max_leaf = max_leaf;
+  fd.sorted = vals_b;
+  fd.prim = bx;
+  fd.child = rt.child;
+  fd.range = rt.range;
+  fd.nlo = rf.nlo;
+  fd.nhi = rf.nhi;
+  fd.nodes = d_nodes;
+  fd.next_count = d_next;
+  uint32_t count = 1, base = 0, depth = 0;
+  uint32_t *q_in = queue_a, *q_out = queue_b;
+  while (count) {
+    if (base + count > n) { res.error = "wide-node pool exhausted"; return -1; }
+    BCHK(hipMemsetAsync(d_next, 0, 8, stream));
+    fd.queue = q_in;
+    fd.count = count;
+    fd.base = base;
+    fd.next_queue = q_out;
+    fd.next_base = base + count;
+    hipLaunchKernelGGL(k_fold_level, dim3((count + 63) / 64), dim3(64), 0, stream, fd);
+    BCHK(hipGetLastError());
+    uint32_t h_next[2] = {0, 0};
+    BCHK(hipMemcpyAsync(h_next, d_next, 8, hipMemcpyDeviceToHost, stream));
+    BCHK(hipStreamSynchronize(stream));
+    if (h_next[1]) { res.error = "scene extent too large for the quantised tree"; return 1; }
+    base += count;
+    count = h_next[0];
+    std::swap(q_in, q_out);
+    if (count) depth++;
+    if (depth > 200) { res.error = "own tree deeper than 200 wide levels"; return 1; }
+  }
+  BCHK(hipEventRecord(ev[3], stream));
+  res.n_nodes = base;
+  res.depth8 = depth;
+  res.nodes_bytes = (size_t) base * 96;
+  res.tris_bytes = (size_t) n * 48;
+  void *out_nodes = nullptr, *out_tris = nullptr;
+  BCHK(hipMalloc(&out_nodes, res.nodes_bytes));
+  if (hipMalloc(&out_tris, res.tris_bytes) != hipSuccess) {
+    (void) hipFree(out_nodes);
+    res.error = "out of device memory";
+    return -1;
+  }
+  hipError_t e1 = hipMemcpyAsync(out_nodes, d_nodes, res.nodes_bytes, hipMemcpyDeviceToDevice, stream);
+  hipLaunchKernelGGL(k_gather_records, dim3((3 * n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, (const uint4 *) tris_dev,
+                     vals_b, n, (uint4 *) out_tris);
+  hipError_t e2 = hipGetLastError();
+  hipError_t e3 = hipEventRecord(ev[4], stream);
+  hipError_t e4 = hipStreamSynchronize(stream);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+    (void) hipFree(out_nodes);
+    (void) hipFree(out_tris);
+    res.error = std::string("device build: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4);
+    return -1;
+  }
+  res.nodes8q = out_nodes;
+  res.trisf = out_tris;
+  for (int k = 0; k < 4; k++) (void) hipEventElapsedTime(&res.ms[k], ev[k], ev[k + 1]);
+  return 0;
+}
+
+}  // namespace mirt

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/mirt.h"
+#include "device_build.hpp"
 #include "host_bvh.hpp"
 #include "host_film.hpp"
 #include "kernels.hpp"
@@ -114,6 +115,9 @@ struct mirt_scene {
   bool has_microfacet = false;
   bool has_spheres = false;
   bool fast_ok = true;                   // false: the SAH tree could not be built (non-finite vertices): traversal 0 runs as 1
+  uint32_t own_builder = 0;              // 0 host binned SAH, 1 device (build.hip)
+  uint32_t n_nodes8 = 0, depth8 = 0;
+  float build_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big, trisf, nodes8q;
   uint32_t ovf_depth = 0;
   uint32_t trace_threads = 0;
@@ -222,6 +226,22 @@ int mirt_scene_create(const float *tri_pos, const float *tri_nrm, const uint32_t
 int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, const uint8_t *prim_type,
                             uint32_t n_tris, const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights,
                             uint32_t n_lights, uint32_t leaf_size, mirt_scene **out) {
+  return mirt_scene_create_opts(tri_pos, tri_nrm, tri_mat, prim_type, n_tris, mats, n_mats, lights, n_lights, leaf_size, nullptr,
+                                out);
+}
+
+int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, const uint8_t *prim_type,
+                           uint32_t n_tris, const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights,
+                           uint32_t n_lights, uint32_t leaf_size, const mirt_build_options *build, mirt_scene **out) {
+  uint32_t builder = 0;
+  if (build) {
+    builder = build->own_tree_builder;
+  } else if (const char *e = getenv("MIRT_BUILDER")) {
+    builder = (!strcmp(e, "device") || !strcmp(e, "1")) ? 1u : 0u;
+  }
+  if (builder > 1) return fail(MIRT_E_ARG, "own_tree_builder must be 0 (host) or 1 (device)");
+  using clk = std::chrono::steady_clock;
+  auto ms_since = [](clk::time_point t) { return std::chrono::duration<float, std::milli>(clk::now() - t).count(); };
   if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
   if (!out) return fail(MIRT_E_ARG, "out is null");
   *out = nullptr;
@@ -234,8 +254,12 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
   }
   auto *s = new mirt_scene();
   try {
+    auto t0 = clk::now();
     build_reference_bvh2(tri_pos, prim_type, n_tris, leaf_size, s->bvh);
+    s->build_ms[0] = ms_since(t0);
+    t0 = clk::now();
     collapse_to_wide(s->bvh);
+    s->build_ms[1] = ms_since(t0);
   } catch (const std::exception &ex) {
     delete s;
     return fail(MIRT_E_LIMIT, ex.what());
@@ -276,16 +300,20 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
     memcpy(m + 10, &o, 4);
     memcpy(m + 11, &kind, 4);
   }
-  // the ordered traversal's own tree (binned SAH) over the same triangles, in its own order
-  std::vector<float> trif((size_t) n_tris * 12);
-  {
-    std::vector<float> flat_pos((size_t) n_tris * 9);
-    std::vector<uint8_t> flat_type;
-    if (prim_type) flat_type.resize(n_tris);
-    for (uint32_t f = 0; f < n_tris; f++) {
-      memcpy(&flat_pos[(size_t) f * 9], tri_pos + 9 * (size_t) s->bvh.flat_to_orig[f], 9 * sizeof(float));
-      if (prim_type) flat_type[f] = prim_type[s->bvh.flat_to_orig[f]];
-    }
+  // the ordered traversal's own tree over the same primitives, in its own order: binned SAH on the host, or the device builder
+  std::vector<float> trif;
+  std::vector<float> flat_pos((size_t) n_tris * 9);
+  std::vector<uint8_t> flat_type;
+  if (prim_type) flat_type.resize(n_tris);
+  for (uint32_t f = 0; f < n_tris; f++) {
+    memcpy(&flat_pos[(size_t) f * 9], tri_pos + 9 * (size_t) s->bvh.flat_to_orig[f], 9 * sizeof(float));
+    if (prim_type) flat_type[f] = prim_type[s->bvh.flat_to_orig[f]];
+  }
+  if (builder == 1 && n_tris < 2) builder = 0;
+  s->own_builder = builder;
+  if (builder == 0) {
+    auto t0 = clk::now();
+    trif.resize((size_t) n_tris * 12);
     try {
       build_fast_tree(flat_pos.data(), prim_type ? flat_type.data() : nullptr, n_tris, s->bvh);
     } catch (const std::exception &) {
@@ -296,6 +324,9 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
     if (s->fast_ok)
       for (uint32_t j = 0; j < n_tris; j++)
         memcpy(&trif[(size_t) j * 12], &tri[(size_t) s->bvh.fast_to_flat[j] * 12], 12 * sizeof(float));
+    s->n_nodes8 = (uint32_t) (s->bvh.nodes8q.size() / (sizeof(Node8Q) / 4));
+    s->depth8 = s->bvh.depth8;
+    s->build_ms[2] = ms_since(t0);
   }
   // materials: mirt_bsdf records (9 dwords) padded to three float4
   std::vector<float> mats_padded((size_t) n_mats * 12, 0.f);
@@ -308,18 +339,51 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
     if (b.ensure(bytes) != hipSuccess) return false;
     return hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
   };
+  auto t_up = clk::now();
   bool ok = up(s->tris, tri.data(), tri.size() * 4) && up(s->tri_nrm, nrm.data(), nrm.size() * 4) &&
             up(s->nodes4, s->bvh.nodes4.data(), s->bvh.nodes4.size() * sizeof(Node4)) &&
             up(s->nodes2, s->bvh.nodes2.data(), s->bvh.nodes2.size() * sizeof(Node2)) &&
-            up(s->trisf, trif.data(), trif.size() * 4) &&
-            up(s->nodes8q, s->bvh.nodes8q.empty() ? (const void *) tri.data() : (const void *) s->bvh.nodes8q.data(),
-               s->bvh.nodes8q.empty() ? 16 : s->bvh.nodes8q.size() * 4) &&
             up(s->mats, mats_padded.data(), mats_padded.size() * 4) &&
             up(s->big, s->bvh.big.empty() ? (const void *) mats : (const void *) s->bvh.big.data(), s->bvh.big.empty() ? 8 : s->bvh.big.size() * 4) &&
             up(s->lights, lights ? (const void *) lights : (const void *) mats, n_lights ? (size_t) n_lights * sizeof(mirt_light) : 4);
+  if (ok && builder == 0)
+    ok = up(s->trisf, trif.data(), trif.size() * 4) &&
+         up(s->nodes8q, s->bvh.nodes8q.empty() ? (const void *) tri.data() : (const void *) s->bvh.nodes8q.data(),
+            s->bvh.nodes8q.empty() ? 16 : s->bvh.nodes8q.size() * 4);
+  s->build_ms[7] = ms_since(t_up);
+  if (ok && builder == 1) {
+    auto t0 = clk::now();
+    DeviceTree dt;
+    uint32_t max_leaf = 3;
+    if (const char *e = getenv("MIRT_FAST_LEAF")) {
+      int v = atoi(e);
+      if (v >= 1 && v <= (int) LEAF_MAX) max_leaf = (uint32_t) v;
+    }
+    const int rc_b = build_fast_tree_device(flat_pos.data(), prim_type ? flat_type.data() : nullptr, s->tris.p, n_tris, max_leaf,
+                                            G.stream, dt);
+    if (rc_b < 0) {
+      rc = fail(MIRT_E_DEVICE, "device tree build failed: " + dt.error);
+      s->release_all();
+      delete s;
+      return rc;
+    }
+    if (rc_b > 0) {                                        // as for the host builder: traversal 0 runs as 1
+      s->fast_ok = false;
+      ok = s->trisf.ensure(16) == hipSuccess && s->nodes8q.ensure(16) == hipSuccess;
+    } else {
+      s->nodes8q.p = dt.nodes8q;
+      s->nodes8q.bytes = dt.nodes_bytes;
+      s->trisf.p = dt.trisf;
+      s->trisf.bytes = dt.tris_bytes;
+      s->n_nodes8 = dt.n_nodes;
+      s->depth8 = dt.depth8;
+      for (int k = 0; k < 4; k++) s->build_ms[3 + k] = dt.ms[k];
+    }
+    s->build_ms[2] = ms_since(t0);
+  }
   if (ok) {
     s->trace_threads = (uint32_t) (G.n_cu * G.blocks_per_cu * TRACE_BLOCK);
-    int need = std::max(3 * ((int) s->bvh.depth4 + 2), 7 * ((int) s->bvh.depth8 + 2)) - LDS_STACK + 1;
+    int need = std::max(3 * ((int) s->bvh.depth4 + 2), 7 * ((int) s->depth8 + 2)) - LDS_STACK + 1;
     s->ovf_depth = (uint32_t) (need > 1 ? need : 1);
     // four regions: the closest-hit and the shadow launch of an iteration run concurrently, in each of two pipes
     ok = s->ovf.ensure(4 * (size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
@@ -351,6 +415,24 @@ int mirt_scene_info(const mirt_scene *s, uint32_t info[8]) {
   info[5] = s->n_mats;
   info[6] = s->n_lights;
   info[7] = (uint32_t) (s->device_bytes() / 1024);
+  return MIRT_OK;
+}
+
+int mirt_scene_build_times(const mirt_scene *s, float ms[8]) {
+  if (!s || !ms) return fail(MIRT_E_ARG, "null argument");
+  memcpy(ms, s->build_ms, sizeof s->build_ms);
+  return MIRT_OK;
+}
+
+int mirt_scene_own_tree(const mirt_scene *s, uint32_t counts[4], uint32_t *nodes8q_out, uint32_t *prims_out) {
+  if (!s || !counts) return fail(MIRT_E_ARG, "null argument");
+  counts[0] = s->fast_ok ? s->n_nodes8 : 0;
+  counts[1] = s->depth8;
+  counts[2] = s->n_tris;
+  counts[3] = s->own_builder;
+  if (!s->fast_ok) return MIRT_OK;
+  if (nodes8q_out) HIPCHK(hipMemcpy(nodes8q_out, s->nodes8q.p, (size_t) s->n_nodes8 * sizeof(Node8Q), hipMemcpyDeviceToHost));
+  if (prims_out) HIPCHK(hipMemcpy(prims_out, s->trisf.p, (size_t) s->n_tris * 48, hipMemcpyDeviceToHost));
   return MIRT_OK;
 }
 

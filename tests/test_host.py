@@ -102,56 +102,18 @@ def test_sphere_scenes_build_the_reference_tree(oracle):
         assert (b["nodes2"] == on).all() and (b["flat"] == of).all()
 
 
-def _prim_box(rec, is_sphere):
-    if is_sphere:
-        return rec[:3] - rec[3], rec[:3] + rec[3]
-    p = rec.reshape(3, 3)
-    return p.min(0), p.max(0)
-
-
 @pytest.mark.parametrize("make", [lambda: scenes.cornell_scene(2), lambda: scenes.conference_scene(20000),
                                   lambda: scenes.random_soup(37, 2), lambda: scenes.sphere_soup(300, 60, 3),
                                   lambda: scenes.random_soup(3, 1)])
 def test_quantised_tree_boxes_contain_their_primitives(make):
-    """The ordered traversal's 8-wide tree: every child box, decoded exactly as the kernel does (p + q * 2^(e-127)), contains
-    the child's primitives; every primitive is in exactly one leaf; leaves hold 1..3 primitives."""
+    """The ordered traversal's 8-wide tree (host builder): every child box, decoded exactly as the kernel does, contains the
+    child's primitives; every primitive is in exactly one leaf; leaves hold 1..3 primitives (tests/treecheck.py)."""
+    from treecheck import check_own_tree
     sc = make()
     b = capi.bvh_build_host(sc.pos, 4, sc.ptype)
-    nodes, f2f = b["nodes8q"], b["fast_to_flat"]
-    flat_pos = sc.pos[b["flat"]].astype(np.float64)
     flat_sph = (sc.ptype[b["flat"]] == 1) if sc.ptype is not None else np.zeros(sc.n, bool)
-    assert sorted(f2f.tolist()) == list(range(sc.n))
-    seen = np.zeros(sc.n, int)
-
-    def prims_under(node):
-        out = []
-        for k in range(8):
-            ref = int(nodes[node][4 + k])
-            if ref == 0xFFFFFFFF:
-                continue
-            if ref & 0x80000000:
-                start, cnt = ref & ((1 << 27) - 1), (ref >> 27) & 15
-                sub = list(range(start, start + cnt))
-                assert 1 <= cnt <= 3
-                for j in sub:
-                    seen[j] += 1
-            else:
-                sub = prims_under(ref)
-            # decode child k's box
-            p = nodes[node][:3].view(np.float32).astype(np.float64)
-            ex = [(int(nodes[node][3]) >> (8 * a)) & 0xFF for a in range(3)]
-            step = np.array([2.0 ** (e - 127) for e in ex])
-            q = nodes[node][12:24].view(np.uint8).reshape(6, 8)       # qlo_x qlo_y qlo_z qhi_x qhi_y qhi_z
-            lo = p + q[0:3, k] * step
-            hi = p + q[3:6, k] * step
-            for j in sub:
-                plo, phi = _prim_box(flat_pos[f2f[j]], flat_sph[f2f[j]])
-                assert (plo >= lo).all() and (phi <= hi).all(), (node, k, j)
-            out += sub
-        return out
-
-    assert sorted(prims_under(0)) == list(range(sc.n))
-    assert (seen == 1).all()
+    depth = check_own_tree(b["nodes8q"], b["fast_to_flat"], sc.pos[b["flat"]], flat_sph, sc.n)
+    assert depth == b["depth8"]
 
 
 def test_single_leaf_scene():

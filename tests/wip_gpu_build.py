@@ -1,0 +1,104 @@
+"""Device builder of the ordered traversal's own tree (raytracer_amd/csrc/build.hip) against the same
+bars as the host builder: structure (conservative boxes, every primitive once), hit parity with the reference through the
+C oracle, films identical to the host-built scene's.  Need a real MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from raytracer_amd import scenes
+from test_gpu_parity import SCENES, SPHERE_SCENES, random_rays
+from treecheck import check_own_tree
+
+pytestmark = pytest.mark.gpu
+
+BUILD_SCENES = {
+    "cornell_mixed": lambda: scenes.cornell_scene(2, "mixed"),
+    "soup37": lambda: scenes.random_soup(37, 2),
+    "soup3": lambda: scenes.random_soup(3, 1),
+    "soup2": lambda: scenes.random_soup(2, 4),
+    "conf20k": lambda: scenes.conference_scene(20000),
+    "sphere_soup": lambda: scenes.sphere_soup(300, 60, 3),
+    "blob64": lambda: scenes.blob_scene(64, 32),
+}
+
+
+@pytest.mark.parametrize("key", list(BUILD_SCENES))
+def test_device_tree_structure(mirt, key):
+    sc = BUILD_SCENES[key]()
+    s = mirt.Scene(sc, builder="device")
+    counts, nodes, prims = s.own_tree()
+    assert counts["builder"] == 1 and counts["prims"] == sc.n and counts["nodes"] >= 1
+    _, flat = s.bvh2()
+    flat_sph = (sc.ptype[flat] == 1) if sc.ptype is not None else np.zeros(sc.n, bool)
+    f2f = prims[:, 9]
+    depth = check_own_tree(nodes, f2f, sc.pos[flat], flat_sph, sc.n)
+    assert depth == counts["depth"]
+    # the gathered records are the flat-order records (host-built scene: the same records in SAH order)
+    h = mirt.Scene(sc, builder="host")
+    hc, _, hprims = h.own_tree()
+    assert hc["builder"] == 0
+    assert (prims[np.argsort(f2f)] == hprims[np.argsort(hprims[:, 9])]).all()
+    s.close()
+    h.close()
+
+
+@pytest.mark.parametrize("key", ["cornell_mixed", "soup500", "conf20k", "sphere_soup", "known_answer"])
+def test_device_tree_traces_like_the_reference(mirt, oracle, key):
+    """Traversal 0 over the device-built tree: closest hits (index and t bits) and occlusion bit-exact with the reference."""
+    sc = (SCENES.get(key) or SPHERE_SCENES[key])()
+    oracle.load(sc)
+    s = mirt.Scene(sc, builder="device")
+    for unit in (False, True):
+        rays = random_rays(sc, 30000, 15 + unit, unit)
+        ci, ct, _ = oracle.trace(rays, normals=True)
+        ai, _ = oracle.trace(rays, anyhit=True)
+        gi, gt, _ = s.trace(rays, traversal=0, bary=True)
+        assert (gi == ci).all() and (gt == ct).all(), f"closest, unit={unit}: {(gi != ci).sum()} differ"
+        hi, _ = s.trace(rays, anyhit=True, traversal=0)
+        assert (hi == ai).all()
+    s.close()
+
+
+def test_device_and_host_built_scenes_render_the_same_film(mirt):
+    """The tree is invisible in the result: same accumulators, bit for bit, whoever built it."""
+    import torch
+    sc = scenes.conference_scene(20000)
+    w, h = 320, 180
+    out = []
+    for builder in ("host", "device"):
+        s = mirt.Scene(sc, builder=builder)
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        st = s.render_accum(w, h, acc.data_ptr(), spp=8, depth=6, rng_mode=1)
+        assert st["traversal_used"] == 0
+        out.append((acc.cpu(), st["closest_rays"], st["shadow_rays"]))
+        s.close()
+    assert out[0][1:] == out[1][1:]
+    assert torch.equal(out[0][0], out[1][0])
+
+
+def test_device_tree_one_million_triangles(mirt):
+    """buddha* (1 046 530 triangles) at 1080p: 2 M primary hits of the ordered traversal over the device-built tree equal the
+    reference walk's; build times of both builders are printed (pytest -s) for DESIGN.md."""
+    sc = scenes.blob_scene(1024, 512, "buddha*")
+    sc.camera = sc.camera.for_aspect(1920, 1080)
+    s = mirt.Scene(sc, builder="device")
+    bt = s.build_times()
+    counts, _, _ = s.own_tree()
+    print("device builder:", counts, {k: round(v, 2) for k, v in bt.items()})
+    i2, t2 = s.primary_hits(1920, 1080, traversal=2)
+    i0, t0 = s.primary_hits(1920, 1080, traversal=0)
+    assert (i0 == i2).all() and (t0 == t2).all(), f"{(i0 != i2).sum()} differ"
+    assert bt["own_tree_ms"] < 500 and bt["dev_fold_ms"] > 0
+    s.close()
+
+
+def test_non_finite_scene_falls_back_like_the_host_builder(mirt):
+    sc = scenes.random_soup(50, 3)
+    sc.pos = sc.pos.copy()
+    sc.pos[7, 4] = np.inf
+    s = mirt.Scene(sc, builder="device")
+    counts, _, _ = s.own_tree()
+    assert counts["nodes"] == 0                       # no own tree: traversal 0 runs as 1, as with the host builder
+    idx, _ = s.primary_hits(32, 32, traversal=0)
+    idx1, _ = s.primary_hits(32, 32, traversal=1)
+    assert (idx == idx1).all()
+    s.close()
