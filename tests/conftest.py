@@ -10,6 +10,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+try:                       # before libmirt.so is loaded: torch ships its own HIP runtime, and whichever copy is loaded first
+    import torch  # noqa: F401  is the one that sees the GPU (tests that hand torch buffers to libmirt need both to)
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
