@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -274,12 +275,14 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
 
   // triangles in the reference's flat order: (p1, e1, e2) for the intersector, (n1, n2, n3, material, original id) for shading
   std::vector<float> tri((size_t) n_tris * 12), nrm((size_t) n_tris * 12);
-  for (uint32_t f = 0; f < n_tris; f++) {
+  std::atomic<bool> sphere_seen{false};
+  parallel_for(n_tris, [&](size_t f0, size_t f1) {
+  for (uint32_t f = (uint32_t) f0; f < (uint32_t) f1; f++) {
     const uint32_t o = s->bvh.flat_to_orig[f];
     const float *p = tri_pos + 9 * (size_t) o, *q = tri_nrm + 9 * (size_t) o;
     float *t = &tri[(size_t) f * 12], *m = &nrm[(size_t) f * 12];
     const uint32_t kind = (prim_type && prim_type[o] == 1) ? 1u : 0u;  // word 10 of both records: 0 triangle, 1 sphere
-    if (kind) s->has_spheres = true;
+    if (kind) sphere_seen.store(true, std::memory_order_relaxed);
     if (kind) {
       t[0] = p[0]; t[1] = p[1]; t[2] = p[2];                          // origin
       t[3] = p[3];                                                    // r
@@ -300,15 +303,19 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
     memcpy(m + 10, &o, 4);
     memcpy(m + 11, &kind, 4);
   }
+  });
+  s->has_spheres = sphere_seen.load();
   // the ordered traversal's own tree over the same primitives, in its own order: binned SAH on the host, or the device builder
   std::vector<float> trif;
   std::vector<float> flat_pos((size_t) n_tris * 9);
   std::vector<uint8_t> flat_type;
   if (prim_type) flat_type.resize(n_tris);
-  for (uint32_t f = 0; f < n_tris; f++) {
-    memcpy(&flat_pos[(size_t) f * 9], tri_pos + 9 * (size_t) s->bvh.flat_to_orig[f], 9 * sizeof(float));
-    if (prim_type) flat_type[f] = prim_type[s->bvh.flat_to_orig[f]];
-  }
+  parallel_for(n_tris, [&](size_t f0, size_t f1) {
+    for (size_t f = f0; f < f1; f++) {
+      memcpy(&flat_pos[f * 9], tri_pos + 9 * (size_t) s->bvh.flat_to_orig[f], 9 * sizeof(float));
+      if (prim_type) flat_type[f] = prim_type[s->bvh.flat_to_orig[f]];
+    }
+  });
   if (builder == 1 && n_tris < 2) builder = 0;
   s->own_builder = builder;
   if (builder == 0) {
@@ -322,8 +329,10 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
       s->bvh.depth8 = 0;
     }
     if (s->fast_ok)
-      for (uint32_t j = 0; j < n_tris; j++)
-        memcpy(&trif[(size_t) j * 12], &tri[(size_t) s->bvh.fast_to_flat[j] * 12], 12 * sizeof(float));
+      parallel_for(n_tris, [&](size_t j0, size_t j1) {
+        for (size_t j = j0; j < j1; j++)
+          memcpy(&trif[j * 12], &tri[(size_t) s->bvh.fast_to_flat[j] * 12], 12 * sizeof(float));
+      });
     s->n_nodes8 = (uint32_t) (s->bvh.nodes8q.size() / (sizeof(Node8Q) / 4));
     s->depth8 = s->bvh.depth8;
     s->build_ms[2] = ms_since(t0);

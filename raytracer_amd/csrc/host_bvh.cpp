@@ -2,6 +2,7 @@
 // See host_bvh.hpp.  Compiled without FMA contraction: every float here must round as the reference's g++ build does.
 #include "host_bvh.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -13,11 +14,8 @@
 #include <thread>
 
 namespace mirt {
-namespace {
 
-// Both top-down builders hand the two halves of a large range to two threads for the first few levels (the halves are
-// independent: disjoint ranges of `order`, node records drawn from a pre-sized pool).  The trees do not depend on it.
-int fork_levels() {
+unsigned host_threads() {
   unsigned t = std::thread::hardware_concurrency();
   if (const char *e = std::getenv("OMP_NUM_THREADS")) {       // the GPU box's CPU share (nproc shows the whole machine there)
     int v = std::atoi(e);
@@ -27,7 +25,36 @@ int fork_levels() {
     int v = std::atoi(e);
     if (v >= 1) t = (unsigned) v;
   }
+  if (t < 1) t = 1;
   if (t > 64) t = 64;
+  return t;
+}
+
+void parallel_for(size_t n, const std::function<void(size_t, size_t)> &body, size_t min_chunk) {
+  size_t parts = host_threads();
+  if (n / (min_chunk ? min_chunk : 1) < parts) parts = n / (min_chunk ? min_chunk : 1);
+  if (parts <= 1) {
+    if (n) body(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err(parts);
+  for (size_t k = 0; k < parts; k++) {
+    const size_t b = n * k / parts, e = n * (k + 1) / parts;
+    th.emplace_back([&, k, b, e] {
+      try { body(b, e); } catch (...) { err[k] = std::current_exception(); }
+    });
+  }
+  for (auto &x: th) x.join();
+  for (auto &x: err) if (x) std::rethrow_exception(x);
+}
+
+namespace {
+
+// Both top-down builders hand the two halves of a large range to two threads for the first few levels (the halves are
+// independent: disjoint ranges of `order`, node records drawn from a pre-sized pool).  The trees do not depend on it.
+int fork_levels() {
+  const unsigned t = host_threads();
   int d = 0;
   while ((1u << d) < 2 * t && t > 1) d++;                      // about two tasks per thread
   return d;
@@ -41,6 +68,34 @@ struct StageClock {                                            // MIRT_BUILD_TIM
     fprintf(stderr, "[mirt build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
     t = n;
   }
+};
+// Node pool of a top-down builder: room for the worst case (2n - 1 records), but pages are only touched as records are
+// handed out (a value-initialised std::vector of that size costs more than the build of a small tree).
+template<class T>
+struct Pool {
+  T *p = nullptr;
+  size_t cap = 0;
+  std::atomic<uint32_t> next{0};
+  Pool() = default;
+  Pool(const Pool &) = delete;
+  Pool &operator=(const Pool &) = delete;
+  ~Pool() { std::free(p); }
+  void reserve(size_t n) {
+    std::free(p);
+    p = (T *) std::malloc(n * sizeof(T));
+    if (!p) throw std::bad_alloc();
+    cap = n;
+    next = 0;
+  }
+  uint32_t take() {
+    const uint32_t id = next.fetch_add(1);
+    if (id >= cap) throw std::runtime_error("node pool exhausted");
+    new (&p[id]) T();
+    return id;
+  }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+  size_t size() const { return next.load(); }
 };
 constexpr uint32_t FORK_MIN = 16384;                           // primitives below which a range is not worth a thread
 
@@ -85,18 +140,19 @@ struct Builder {
     Box bb;
     int32_t l = -1, r = -1;
     uint32_t start = 0, end = 0;
+    uint32_t n_nodes = 1, n_prims = 0, height = 0;      // of the subtree: lets flatten() place subtrees independently
   };
-  std::vector<TNode> tree;               // pool of 2n records; ids are handed out by `next` (flatten() assigns the final order)
-  std::atomic<uint32_t> next{0};
+  Pool<TNode> tree;                       // flatten() assigns the final order
   int fork_depth = 0;
 
   void prepare(uint32_t n) {
     pbox.resize(n);
     pcent.resize(3 * (size_t) n);
     order.resize(n);
-    tree.resize(2 * (size_t) n);
+    tree.reserve(2 * (size_t) n);
     fork_depth = fork_levels();
-    for (uint32_t i = 0; i < n; i++) {
+    parallel_for(n, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; i++) {
       const float *p = pos + 9 * (size_t) i;
       Box b;
       if (ptype && ptype[i] == 1) {                      // SPHERE: origin -/+ (r, r, r)   primitives.cuh:166-169
@@ -118,8 +174,9 @@ struct Builder {
       pbox[i] = b;
       const float rc = (float) (1.0 / (double) 2.0f);    // Vector3f::operator/(float)  Vector3f.cuh:106-109
       for (int a = 0; a < 3; a++) pcent[3 * (size_t) i + a] = rc * (b.lo[a] + b.hi[a]);
-      order[i] = i;
+      order[i] = (uint32_t) i;
     }
+    });
   }
 
   int32_t construct(uint32_t start, uint32_t end, int depth = 0) {      // bvh.cuh:187-225
@@ -135,9 +192,9 @@ struct Builder {
         bb.hi[a] = maxf(bb.hi[a], b.hi[a]);
       }
     }
-    const int32_t id = (int32_t) next.fetch_add(1);
-    if ((size_t) id >= tree.size()) throw std::runtime_error("node pool exhausted");
+    const int32_t id = (int32_t) tree.take();
     tree[id].bb = bb;
+    tree[id].n_prims = end - start;
     if ((int64_t) end - (int64_t) start <= (int64_t) max_leaf) {
       tree[id].start = start;
       tree[id].end = end;
@@ -182,18 +239,14 @@ struct Builder {
               [&] { r = construct(middle, end, depth + 1); });
     tree[id].l = l;
     tree[id].r = r;
+    tree[id].n_nodes = 1 + tree[l].n_nodes + tree[r].n_nodes;
+    tree[id].height = 1 + std::max(tree[l].height, tree[r].height);   // get_max_depth, bvh.cuh:297-300
     return id;
   }
 
-  uint32_t depth_of(int32_t id, uint32_t d) const {      // bvh.cuh:297-300
-    if (tree[id].l < 0) return d;
-    uint32_t a = depth_of(tree[id].l, d + 1), b = depth_of(tree[id].r, d + 1);
-    return a < b ? b : a;
-  }
-
-  void flatten(int32_t id, HostBVH &out, uint32_t &prim_start) {   // bvh.cuh:272-290
-    uint32_t n_idx = (uint32_t) out.nodes2.size();
-    out.nodes2.emplace_back();
+  // bvh.cuh:272-290: pre-order, the right subtree first (nodes and primitives alike).  With the subtree sizes known the
+  // two subtrees have fixed places in the output and can be written independently.
+  void flatten(int32_t id, HostBVH &out, uint32_t n_idx, uint32_t prim_start, int depth = 0) {
     for (int a = 0; a < 3; a++) {
       out.nodes2[n_idx].minp[a] = tree[id].bb.lo[a];
       out.nodes2[n_idx].maxp[a] = tree[id].bb.hi[a];
@@ -203,10 +256,13 @@ struct Builder {
       out.nodes2[n_idx].w1 = prim_start;
       for (uint32_t p = tree[id].start; p < tree[id].end; p++) out.flat_to_orig[prim_start++] = order[p];
     } else {
-      out.nodes2[n_idx].w1 = (uint32_t) out.nodes2.size();          // idx_right = ++node_start
-      flatten(tree[id].r, out, prim_start);
-      out.nodes2[n_idx].w0 = (uint32_t) out.nodes2.size();          // idx_left
-      flatten(tree[id].l, out, prim_start);
+      const int32_t l = tree[id].l, r = tree[id].r;
+      const uint32_t right_idx = n_idx + 1, left_idx = right_idx + tree[r].n_nodes;
+      out.nodes2[n_idx].w1 = right_idx;                             // idx_right = ++node_start
+      out.nodes2[n_idx].w0 = left_idx;                              // idx_left
+      fork_join(depth < fork_depth && tree[id].n_prims >= FORK_MIN,
+                [&] { flatten(r, out, right_idx, prim_start, depth + 1); },
+                [&] { flatten(l, out, left_idx, prim_start + tree[r].n_prims, depth + 1); });
     }
   }
 };
@@ -310,12 +366,10 @@ void build_reference_bvh2(const float *tri_pos, const uint8_t *prim_type, uint32
   clk.lap("reference: boxes, centroids");
   int32_t root = bd.construct(0, n);
   clk.lap("reference: construct");
-  out.nodes2.clear();
-  out.nodes2.reserve(bd.next.load());
+  out.nodes2.assign(bd.tree[root].n_nodes, Node2());
   out.flat_to_orig.assign(n, 0);
-  uint32_t prim_start = 0;
-  bd.flatten(root, out, prim_start);
-  out.depth2 = bd.depth_of(root, 0);
+  bd.flatten(root, out, 0, 0);
+  out.depth2 = bd.tree[root].height;
   clk.lap("reference: flatten");
 }
 
@@ -342,14 +396,13 @@ struct SahBuilder {
   std::vector<Box> pbox;
   std::vector<float> cent;
   std::vector<uint32_t> order;
-  std::vector<Node2> &out;                // pool of 2n records, ids from `next`
+  Pool<Node2> &out;
   std::vector<uint32_t> &perm;            // = order when the build is done (a leaf's primitives are its range of `order`)
-  std::atomic<uint32_t> next{0};
   int fork_depth = 0;
   uint32_t max_leaf;
   static constexpr int BINS = 16;
 
-  SahBuilder(std::vector<Node2> &o, std::vector<uint32_t> &p) : out(o), perm(p) {}
+  SahBuilder(Pool<Node2> &o, std::vector<uint32_t> &p) : out(o), perm(p) {}
 
   static float area(const Box &b) {
     float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
@@ -374,9 +427,10 @@ struct SahBuilder {
     pbox.resize(n);
     cent.resize(3 * (size_t) n);
     order.resize(n);
-    out.resize(2 * (size_t) n);
+    out.reserve(2 * (size_t) n);
     fork_depth = fork_levels();
-    for (uint32_t i = 0; i < n; i++) {
+    parallel_for(n, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; i++) {
       const float *p = pos + 9 * (size_t) i;
       Box b = empty();
       if (ptype && ptype[i] == 1) {
@@ -394,8 +448,9 @@ struct SahBuilder {
       }
       pbox[i] = b;
       for (int k = 0; k < 3; k++) cent[3 * (size_t) i + k] = 0.5f * (b.lo[k] + b.hi[k]);
-      order[i] = i;
+      order[i] = (uint32_t) i;
     }
+    });
   }
 
   uint32_t build(uint32_t s, uint32_t e, int depth = 0) {
@@ -408,8 +463,7 @@ struct SahBuilder {
         cb.hi[k] = std::fmax(cb.hi[k], c);
       }
     }
-    const uint32_t id = next.fetch_add(1);
-    if ((size_t) id >= out.size()) throw std::runtime_error("node pool exhausted");
+    const uint32_t id = out.take();
     for (int k = 0; k < 3; k++) { out[id].minp[k] = bb.lo[k]; out[id].maxp[k] = bb.hi[k]; }
     const uint32_t n = e - s;
     if (n <= max_leaf) {
@@ -471,20 +525,14 @@ struct SahBuilder {
   }
 };
 
-uint32_t depth_of_nodes(const std::vector<Node2> &n, uint32_t i, uint32_t d) {
-  if (n[i].w0 & 0x80000000u) return d;
-  uint32_t a = depth_of_nodes(n, n[i].w0, d + 1), b = depth_of_nodes(n, n[i].w1, d + 1);
-  return a < b ? b : a;
-}
-
 }  // namespace
 
 // Folds the binary SAH tree to 8-wide nodes (largest-area child expanded first) and quantises the child boxes.
 struct Collapser8 {
-  const std::vector<Node2> &n2;
+  const Pool<Node2> &n2;
   std::vector<Node8Q> out;
   uint32_t max_depth = 0;
-  explicit Collapser8(const std::vector<Node2> &nodes) : n2(nodes) {}
+  explicit Collapser8(const Pool<Node2> &nodes) : n2(nodes) {}
 
   uint32_t build(uint32_t root_id, uint32_t depth) {
     const uint32_t id = (uint32_t) out.size();
@@ -576,7 +624,7 @@ struct Collapser8 {
 };
 
 void build_fast_tree(const float *tri_pos_flat, const uint8_t *prim_type_flat, uint32_t n, HostBVH &bvh) {
-  std::vector<Node2> n2;
+  Pool<Node2> n2;
   bvh.fast_to_flat.clear();
   SahBuilder sb(n2, bvh.fast_to_flat);
   sb.pos = tri_pos_flat;

@@ -10,9 +10,15 @@
 //     visit leaves exactly as the reference does.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace mirt {
+
+// Threads the host side may use (OMP_NUM_THREADS is the GPU box's CPU share; MIRT_BUILD_THREADS overrides), and a plain
+// blocked loop over [0, n) on them.  Results never depend on the thread count.
+unsigned host_threads();
+void parallel_for(size_t n, const std::function<void(size_t, size_t)> &body, size_t min_chunk = 8192);
 
 struct Node2 {            // = BVHNodeOpt (bvh/bvh.cuh:12-30), 32 bytes
   float minp[3];
