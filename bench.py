@@ -57,7 +57,7 @@ def parse():
                     help="nccl = RCCL, one GPU per rank (what the driver runs); gloo = rehearsal of the N > 1 path on a box "
                          "with fewer GPUs than ranks: ranks share the GPUs and the buffers are summed through host memory")
     ap.add_argument("--split", action="store_true", help="add the per-kernel time split of one extra frame to the roofline object")
-    ap.add_argument("--builder", default=None, choices=["host", "device"],
+    ap.add_argument("--builder", default=None, choices=["host", "device", "ploc"],
                     help="who builds the ordered traversal's own tree (default: the library's, host binned SAH)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)

@@ -151,7 +151,8 @@ class Scene:
     """Owns a mirt_scene handle.  Mirrors what PathTracer::set_scene + the BVH part of raytrace() do."""
 
     def __init__(self, sc, leaf_size=4, builder=None):
-        """builder: None = library default (or MIRT_BUILDER), "host" / "device" = mirt_build_options.own_tree_builder."""
+        """builder: None = library default (or MIRT_BUILDER); "host", "device" (= "lbvh": Morton radix tree on the GPU) or "ploc"
+        (locally-ordered clustering on the GPU) = mirt_build_options.own_tree_builder 0 / 1 / 2."""
         lib = load()
         self.n = sc.n
         self.mats = bsdf_records(sc.mats)
@@ -160,7 +161,7 @@ class Scene:
         ptype = getattr(sc, "ptype", None)
         if builder is not None:
             bo = BuildOptions()
-            bo.own_tree_builder = {"host": 0, "device": 1}[builder]
+            bo.own_tree_builder = {"host": 0, "device": 1, "lbvh": 1, "ploc": 2}[builder]
             _chk(lib.mirt_scene_create_opts(_p(sc.pos), _p(sc.nrm), _p(sc.mat), _p(ptype), C.c_uint32(sc.n), _p(self.mats),
                                             C.c_uint32(len(self.mats)), _p(self.lights) if len(self.lights) else None,
                                             C.c_uint32(len(self.lights)), C.c_uint32(leaf_size), C.byref(bo), C.byref(h)))

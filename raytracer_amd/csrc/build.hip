@@ -14,6 +14,7 @@
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "device_build.hpp"
 #include "host_bvh.hpp"
@@ -210,6 +211,174 @@ __global__ void __launch_bounds__(BLOCK) k_refit(Refit r) {
   }
 }
 
+// ---- PLOC (Meister & Bittner, "Parallel locally-ordered clustering for bounding volume hierarchy construction", TVCG
+// 2018): the clusters, kept in Morton order, each look for the neighbour within PLOC_RADIUS positions whose union with
+// them has the smallest area; mutual nearest neighbours merge; the list is compacted (order kept) and the search repeats
+// until one cluster is left.  Bottom-up with a surface-area criterion: about the traversal cost of a binned SAH tree.
+constexpr int PLOC_RADIUS = 16;
+
+struct Ploc {
+  uint32_t m;
+  const uint32_t *cl_in;                                    // cluster = node reference (LEAF_BIT | sorted position, or inner id)
+  const float4 *lo_in, *hi_in;                              // its box; lo.w carries the primitive count (bits)
+  uint32_t *nn;
+  uint32_t *cl_out, *valid;
+  float4 *lo_out, *hi_out;
+  uint2 *child;
+  float4 *nlo, *nhi;
+  uint32_t *count;
+  uint32_t *parent_inner, *parent_leaf;
+  uint32_t *node_counter;
+};
+
+__device__ __forceinline__ float union_area(const float4 &alo, const float4 &ahi, const float4 &blo, const float4 &bhi) {
+  const float dx = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x), dy = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y),
+              dz = fmaxf(ahi.z, bhi.z) - fminf(alo.z, blo.z);
+  return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_ploc_nn(Ploc p) {
+  __shared__ float4 slo[BLOCK + 2 * PLOC_RADIUS], shi[BLOCK + 2 * PLOC_RADIUS];
+  const int base = (int) (blockIdx.x * BLOCK) - PLOC_RADIUS;
+  for (int t = threadIdx.x; t < BLOCK + 2 * PLOC_RADIUS; t += BLOCK) {
+    const int g = base + t;
+    if (g >= 0 && g < (int) p.m) {
+      slo[t] = p.lo_in[g];
+      shi[t] = p.hi_in[g];
+    }
+  }
+  __syncthreads();
+  const int i = (int) (blockIdx.x * BLOCK + threadIdx.x);
+  if (i >= (int) p.m) return;
+  const float4 mlo = slo[threadIdx.x + PLOC_RADIUS], mhi = shi[threadIdx.x + PLOC_RADIUS];
+  float best_a = INFINITY;
+  int best = -1;
+  // increasing index, strict '<': among equal areas the lowest index wins, which guarantees a mutual pair per pass
+  for (int o = -PLOC_RADIUS; o <= PLOC_RADIUS; o++) {
+    const int g = i + o;
+    if (o == 0 || g < 0 || g >= (int) p.m) continue;
+    const float a = union_area(mlo, mhi, slo[threadIdx.x + PLOC_RADIUS + o], shi[threadIdx.x + PLOC_RADIUS + o]);
+    if (a < best_a || best < 0) {
+      best_a = a;
+      best = g;
+    }
+  }
+  p.nn[i] = (uint32_t) best;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_ploc_merge(Ploc p) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  const bool in = i < p.m;
+  uint32_t j = 0;
+  bool mutual = false;
+  if (in) {
+    j = p.nn[i];
+    mutual = p.nn[j] == i;
+  }
+  const bool leader = in && mutual && i < j;
+  // node ids: one atomic per wave
+  const unsigned long long mask = __ballot(leader);
+  uint32_t id = 0;
+  if (mask) {
+    const int lane = threadIdx.x & 63;
+    const int first = __ffsll((long long) mask) - 1;
+    uint32_t wave_base = 0;
+    if (lane == first) wave_base = atomicAdd(p.node_counter, (uint32_t) __popcll(mask));
+    wave_base = __shfl(wave_base, first);
+    id = wave_base + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+  }
+  if (!in) return;
+  if (leader) {
+    const uint32_t a = p.cl_in[i], b = p.cl_in[j];
+    const float4 alo = p.lo_in[i], ahi = p.hi_in[i], blo = p.lo_in[j], bhi = p.hi_in[j];
+    const uint32_t cnt = __float_as_uint(alo.w) + __float_as_uint(blo.w);
+    const float4 lo = make_float4(fminf(alo.x, blo.x), fminf(alo.y, blo.y), fminf(alo.z, blo.z), __uint_as_float(cnt));
+    const float4 hi = make_float4(fmaxf(ahi.x, bhi.x), fmaxf(ahi.y, bhi.y), fmaxf(ahi.z, bhi.z), 0.f);
+    p.child[id] = make_uint2(a, b);
+    p.nlo[id] = lo;
+    p.nhi[id] = hi;
+    p.count[id] = cnt;
+    if (a & LEAF_BIT) p.parent_leaf[a & ~LEAF_BIT] = id; else p.parent_inner[a] = id;
+    if (b & LEAF_BIT) p.parent_leaf[b & ~LEAF_BIT] = id; else p.parent_inner[b] = id;
+    p.cl_out[i] = id;
+    p.lo_out[i] = lo;
+    p.hi_out[i] = hi;
+    p.valid[i] = 1;
+  } else if (mutual) {
+    p.valid[i] = 0;
+  } else {
+    p.cl_out[i] = p.cl_in[i];
+    p.lo_out[i] = p.lo_in[i];
+    p.hi_out[i] = p.hi_in[i];
+    p.valid[i] = 1;
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_ploc_compact(uint32_t m, const uint32_t *valid, const uint32_t *pos,
+                                                        const uint32_t *cl, const float4 *lo, const float4 *hi,
+                                                        uint32_t *cl_next, float4 *lo_next, float4 *hi_next, uint32_t *m_next) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= m) return;
+  if (valid[i]) {
+    const uint32_t q = pos[i];
+    cl_next[q] = cl[i];
+    lo_next[q] = lo[i];
+    hi_next[q] = hi[i];
+  }
+  if (i == m - 1) *m_next = pos[i] + valid[i];
+}
+
+__global__ void __launch_bounds__(BLOCK) k_ploc_init(uint32_t n, const uint32_t *sorted, Boxes prim, uint32_t *cl, float4 *lo,
+                                                     float4 *hi) {
+  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t q = sorted[j];
+  float4 a = prim.lo[q];
+  a.w = __uint_as_float(1u);
+  cl[j] = LEAF_BIT | j;
+  lo[j] = a;
+  hi[j] = prim.hi[q];
+}
+
+// Depth-first position of every leaf / first position of every inner node: climbing to the root, add the size of the left
+// sibling wherever the path comes up from a right child.
+struct Order {
+  uint32_t n;
+  const uint2 *child;
+  const uint32_t *count, *parent_inner, *parent_leaf;
+};
+__device__ __forceinline__ uint32_t climb(const Order &o, uint32_t me, uint32_t cur) {
+  uint32_t pos = 0;
+  while (cur != 0xFFFFFFFFu) {
+    const uint2 c = o.child[cur];
+    if (c.y == me) pos += (c.x & LEAF_BIT) ? 1u : o.count[c.x];
+    me = cur;
+    cur = o.parent_inner[cur];
+  }
+  return pos;
+}
+__global__ void __launch_bounds__(BLOCK) k_ploc_leaf_order(Order o, const uint32_t *sorted, uint32_t *leaf_pos, uint32_t *sorted_out) {
+  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= o.n) return;
+  const uint32_t pos = climb(o, LEAF_BIT | j, o.parent_leaf[j]);
+  leaf_pos[j] = pos;
+  sorted_out[pos] = sorted[j];
+}
+__global__ void __launch_bounds__(BLOCK) k_ploc_ranges(Order o, const uint32_t *leaf_pos, uint2 *child_rw, uint2 *range) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= o.n - 1) return;
+  const uint32_t first = climb(o, i, o.parent_inner[i]);
+  range[i] = make_uint2(first, first + o.count[i] - 1);
+}
+__global__ void __launch_bounds__(BLOCK) k_ploc_relabel(uint32_t n, const uint32_t *leaf_pos, uint2 *child) {
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n - 1) return;
+  uint2 c = child[i];
+  if (c.x & LEAF_BIT) c.x = LEAF_BIT | leaf_pos[c.x & ~LEAF_BIT];
+  if (c.y & LEAF_BIT) c.y = LEAF_BIT | leaf_pos[c.y & ~LEAF_BIT];
+  child[i] = c;
+}
+
 // ---- fold to 8-wide quantised nodes, one level per launch.  Entry e of the level's queue is the binary-tree reference
 // that becomes wide node base + e; inner children are appended to the next level's queue, whose position is their index.
 struct Fold {
@@ -375,7 +544,7 @@ struct Scratch {                                            // frees what the bu
   } while (0)
 
 int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat_host, const void *tris_dev, uint32_t n,
-                           uint32_t max_leaf, hipStream_t stream, DeviceTree &res) {
+                           uint32_t max_leaf, int method, hipStream_t stream, DeviceTree &res) {
   res = DeviceTree();
   if (n < 2) { res.error = "fewer than two primitives"; return 1; }
   if (max_leaf < 1 || max_leaf > LEAF_MAX) max_leaf = 3;
@@ -415,27 +584,103 @@ int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat
   BCHK(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, n, 0, 63, stream));
   BCHK(hipEventRecord(ev[1], stream));
 
-  Radix rt{};
-  rt.keys = keys_b;
-  rt.n = n;
-  BCHK(sc.get(&rt.child, n));
-  BCHK(sc.get(&rt.range, n));
-  BCHK(sc.get(&rt.parent_inner, n));
-  BCHK(sc.get(&rt.parent_leaf, n));
-  hipLaunchKernelGGL(k_radix_tree, dim3(nb), dim3(BLOCK), 0, stream, rt);
-  Refit rf{};
-  rf.n = n;
-  rf.sorted = vals_b;
-  rf.prim = bx;
-  rf.child = rt.child;
-  rf.parent_inner = rt.parent_inner;
-  rf.parent_leaf = rt.parent_leaf;
-  BCHK(sc.get(&rf.arrived, n));
-  BCHK(sc.get(&rf.nlo, n));
-  BCHK(sc.get(&rf.nhi, n));
-  BCHK(hipMemsetAsync(rf.arrived, 0, (size_t) n * 4, stream));
-  hipLaunchKernelGGL(k_refit, dim3(nb), dim3(BLOCK), 0, stream, rf);
-  BCHK(hipGetLastError());
+  // binary tree over the sorted primitives: child / range / boxes per inner node, `sorted` = leaf position -> flat primitive
+  uint2 *t_child = nullptr, *t_range = nullptr;
+  float4 *t_nlo = nullptr, *t_nhi = nullptr;
+  uint32_t *t_parent_inner = nullptr, *t_parent_leaf = nullptr;
+  const uint32_t *t_sorted = vals_b;
+  uint32_t root_ref = 0;
+  BCHK(sc.get(&t_child, n));
+  BCHK(sc.get(&t_range, n));
+  BCHK(sc.get(&t_parent_inner, n));
+  BCHK(sc.get(&t_parent_leaf, n));
+  BCHK(sc.get(&t_nlo, n));
+  BCHK(sc.get(&t_nhi, n));
+  if (method == 2) {
+    Ploc pl{};
+    uint32_t *cl_x = nullptr, *cl_y = nullptr, *d_pos_scan = nullptr, *d_m = nullptr, *leaf_pos = nullptr, *sorted2 = nullptr;
+    float4 *lo_x = nullptr, *hi_x = nullptr, *lo_y = nullptr, *hi_y = nullptr;
+    BCHK(sc.get(&cl_x, n));
+    BCHK(sc.get(&cl_y, n));
+    BCHK(sc.get(&lo_x, n));
+    BCHK(sc.get(&hi_x, n));
+    BCHK(sc.get(&lo_y, n));
+    BCHK(sc.get(&hi_y, n));
+    BCHK(sc.get(&pl.nn, n));
+    BCHK(sc.get(&pl.valid, n));
+    BCHK(sc.get(&pl.count, n));
+    BCHK(sc.get(&d_pos_scan, n));
+    BCHK(sc.get(&d_m, 2));
+    BCHK(sc.get(&leaf_pos, n));
+    BCHK(sc.get(&sorted2, n));
+    pl.child = t_child;
+    pl.nlo = t_nlo;
+    pl.nhi = t_nhi;
+    pl.parent_inner = t_parent_inner;
+    pl.parent_leaf = t_parent_leaf;
+    pl.node_counter = d_m + 1;
+    BCHK(hipMemsetAsync(d_m, 0, 8, stream));
+    BCHK(hipMemsetAsync(t_parent_inner, 0xFF, (size_t) n * 4, stream));
+    hipLaunchKernelGGL(k_ploc_init, dim3(nb), dim3(BLOCK), 0, stream, n, vals_b, bx, cl_x, lo_x, hi_x);
+    size_t scan_bytes = 0;
+    BCHK(rocprim::exclusive_scan(nullptr, scan_bytes, pl.valid, d_pos_scan, 0u, n, rocprim::plus<uint32_t>(), stream));
+    char *d_scan_tmp = nullptr;
+    BCHK(sc.get(&d_scan_tmp, scan_bytes));
+    uint32_t m = n, passes = 0;
+    while (m > 1) {
+      if (++passes > 8192) { res.error = "PLOC did not converge"; return 1; }
+      const uint32_t mb = (m + BLOCK - 1) / BLOCK;
+      pl.m = m;
+      pl.cl_in = cl_x;
+      pl.lo_in = lo_x;
+      pl.hi_in = hi_x;
+      pl.cl_out = cl_y;
+      pl.lo_out = lo_y;
+      pl.hi_out = hi_y;
+      hipLaunchKernelGGL(k_ploc_nn, dim3(mb), dim3(BLOCK), 0, stream, pl);
+      hipLaunchKernelGGL(k_ploc_merge, dim3(mb), dim3(BLOCK), 0, stream, pl);
+      BCHK(hipGetLastError());
+      size_t sb = scan_bytes;
+      BCHK(rocprim::exclusive_scan(d_scan_tmp, sb, pl.valid, d_pos_scan, 0u, m, rocprim::plus<uint32_t>(), stream));
+      hipLaunchKernelGGL(k_ploc_compact, dim3(mb), dim3(BLOCK), 0, stream, m, pl.valid, d_pos_scan, cl_y, lo_y, hi_y, cl_x, lo_x,
+                         hi_x, d_m);
+      uint32_t m_next = 0;
+      BCHK(hipMemcpyAsync(&m_next, d_m, 4, hipMemcpyDeviceToHost, stream));
+      BCHK(hipStreamSynchronize(stream));
+      if (m_next == 0 || m_next >= m) { res.error = "PLOC made no progress"; return -1; }
+      m = m_next;
+    }
+    BCHK(hipMemcpyAsync(&root_ref, cl_x, 4, hipMemcpyDeviceToHost, stream));
+    Order od{n, t_child, pl.count, t_parent_inner, t_parent_leaf};
+    hipLaunchKernelGGL(k_ploc_leaf_order, dim3(nb), dim3(BLOCK), 0, stream, od, vals_b, leaf_pos, sorted2);
+    hipLaunchKernelGGL(k_ploc_ranges, dim3(nb), dim3(BLOCK), 0, stream, od, leaf_pos, t_child, t_range);
+    hipLaunchKernelGGL(k_ploc_relabel, dim3(nb), dim3(BLOCK), 0, stream, n, leaf_pos, t_child);
+    BCHK(hipGetLastError());
+    t_sorted = sorted2;
+    res.passes = passes;
+  } else {
+    Radix rt{};
+    rt.keys = keys_b;
+    rt.n = n;
+    rt.child = t_child;
+    rt.range = t_range;
+    rt.parent_inner = t_parent_inner;
+    rt.parent_leaf = t_parent_leaf;
+    hipLaunchKernelGGL(k_radix_tree, dim3(nb), dim3(BLOCK), 0, stream, rt);
+    Refit rf{};
+    rf.n = n;
+    rf.sorted = vals_b;
+    rf.prim = bx;
+    rf.child = t_child;
+    rf.parent_inner = t_parent_inner;
+    rf.parent_leaf = t_parent_leaf;
+    rf.nlo = t_nlo;
+    rf.nhi = t_nhi;
+    BCHK(sc.get(&rf.arrived, n));
+    BCHK(hipMemsetAsync(rf.arrived, 0, (size_t) n * 4, stream));
+    hipLaunchKernelGGL(k_refit, dim3(nb), dim3(BLOCK), 0, stream, rf);
+    BCHK(hipGetLastError());
+  }
   BCHK(hipEventRecord(ev[2], stream));
 
   // fold, level by level; at most n - 1 wide nodes (every one but a lone root has two or more children)
@@ -446,19 +691,19 @@ int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat
   BCHK(sc.get(&d_next, 2));
   uint32_t h_flags = 0;
   BCHK(hipMemcpyAsync(&h_flags, d_scene + 6, 4, hipMemcpyDeviceToHost, stream));
-  const uint32_t root_ref = 0;
+  BCHK(hipStreamSynchronize(stream));                        // (root_ref of the PLOC path has arrived)
   BCHK(hipMemcpyAsync(queue_a, &root_ref, 4, hipMemcpyHostToDevice, stream));
   BCHK(hipStreamSynchronize(stream));
   if (h_flags & 1) { res.error = "non-finite vertex: no quantised tree"; return 1; }
   Fold fd{};
   fd.n = n;
   fd.max_leaf = max_leaf;
-  fd.sorted = vals_b;
+  fd.sorted = t_sorted;
   fd.prim = bx;
-  fd.child = rt.child;
-  fd.range = rt.range;
-  fd.nlo = rf.nlo;
-  fd.nhi = rf.nhi;
+  fd.child = t_child;
+  fd.range = t_range;
+  fd.nlo = t_nlo;
+  fd.nhi = t_nhi;
   fd.nodes = d_nodes;
   fd.next_count = d_next;
   uint32_t count = 1, base = 0, depth = 0;
@@ -497,7 +742,7 @@ int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat
   }
   hipError_t e1 = hipMemcpyAsync(out_nodes, d_nodes, res.nodes_bytes, hipMemcpyDeviceToDevice, stream);
   hipLaunchKernelGGL(k_gather_records, dim3((3 * n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, (const uint4 *) tris_dev,
-                     vals_b, n, (uint4 *) out_tris);
+                     t_sorted, n, (uint4 *) out_tris);
   hipError_t e2 = hipGetLastError();
   hipError_t e3 = hipEventRecord(ev[4], stream);
   hipError_t e4 = hipStreamSynchronize(stream);

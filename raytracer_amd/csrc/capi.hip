@@ -238,9 +238,9 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
   if (build) {
     builder = build->own_tree_builder;
   } else if (const char *e = getenv("MIRT_BUILDER")) {
-    builder = (!strcmp(e, "device") || !strcmp(e, "1")) ? 1u : 0u;
+    builder = (!strcmp(e, "device") || !strcmp(e, "1")) ? 1u : (!strcmp(e, "ploc") || !strcmp(e, "2")) ? 2u : 0u;
   }
-  if (builder > 1) return fail(MIRT_E_ARG, "own_tree_builder must be 0 (host) or 1 (device)");
+  if (builder > 2) return fail(MIRT_E_ARG, "own_tree_builder must be 0 (host), 1 (device, Morton radix tree) or 2 (device, PLOC)");
   using clk = std::chrono::steady_clock;
   auto ms_since = [](clk::time_point t) { return std::chrono::duration<float, std::milli>(clk::now() - t).count(); };
   if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
@@ -316,7 +316,7 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
       if (prim_type) flat_type[f] = prim_type[s->bvh.flat_to_orig[f]];
     }
   });
-  if (builder == 1 && n_tris < 2) builder = 0;
+  if (builder >= 1 && n_tris < 2) builder = 0;
   s->own_builder = builder;
   if (builder == 0) {
     auto t0 = clk::now();
@@ -360,7 +360,7 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
          up(s->nodes8q, s->bvh.nodes8q.empty() ? (const void *) tri.data() : (const void *) s->bvh.nodes8q.data(),
             s->bvh.nodes8q.empty() ? 16 : s->bvh.nodes8q.size() * 4);
   s->build_ms[7] = ms_since(t_up);
-  if (ok && builder == 1) {
+  if (ok && builder >= 1) {
     auto t0 = clk::now();
     DeviceTree dt;
     uint32_t max_leaf = 3;
@@ -369,7 +369,7 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
       if (v >= 1 && v <= (int) LEAF_MAX) max_leaf = (uint32_t) v;
     }
     const int rc_b = build_fast_tree_device(flat_pos.data(), prim_type ? flat_type.data() : nullptr, s->tris.p, n_tris, max_leaf,
-                                            G.stream, dt);
+                                            (int) builder, G.stream, dt);
     if (rc_b < 0) {
       rc = fail(MIRT_E_DEVICE, "device tree build failed: " + dt.error);
       s->release_all();

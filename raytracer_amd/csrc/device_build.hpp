@@ -13,7 +13,8 @@ struct DeviceTree {
   size_t nodes_bytes = 0, tris_bytes = 0;
   uint32_t n_nodes = 0;
   uint32_t depth8 = 0;           // levels below the root
-  float ms[4] = {0, 0, 0, 0};    // upload + keys + sort | radix tree + boxes | fold | gather
+  uint32_t passes = 0;           // PLOC merge passes
+  float ms[4] = {0, 0, 0, 0};    // upload + keys + sort | binary tree + boxes | fold | gather
   std::string error;
 };
 
@@ -22,6 +23,7 @@ struct DeviceTree {
 // have a quantised tree (non-finite vertices, extent beyond float range, fewer than two primitives: the caller falls back
 // exactly as for the host builder), -1 on a HIP error.  Synchronises `stream`.
 int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat_host, const void *tris_dev, uint32_t n,
-                           uint32_t max_leaf, hipStream_t stream, DeviceTree &out);
+                           uint32_t max_leaf, int method /* 1 Morton radix tree, 2 PLOC */, hipStream_t stream,
+                           DeviceTree &out);
 
 }  // namespace mirt

@@ -21,12 +21,16 @@ BUILD_SCENES = {
 }
 
 
+DEVICE_BUILDERS = {"device": 1, "ploc": 2}
+
+
+@pytest.mark.parametrize("builder", list(DEVICE_BUILDERS))
 @pytest.mark.parametrize("key", list(BUILD_SCENES))
-def test_device_tree_structure(mirt, key):
+def test_device_tree_structure(mirt, key, builder):
     sc = BUILD_SCENES[key]()
-    s = mirt.Scene(sc, builder="device")
+    s = mirt.Scene(sc, builder=builder)
     counts, nodes, prims = s.own_tree()
-    assert counts["builder"] == 1 and counts["prims"] == sc.n and counts["nodes"] >= 1
+    assert counts["builder"] == DEVICE_BUILDERS[builder] and counts["prims"] == sc.n and counts["nodes"] >= 1
     _, flat = s.bvh2()
     flat_sph = (sc.ptype[flat] == 1) if sc.ptype is not None else np.zeros(sc.n, bool)
     f2f = prims[:, 9]
@@ -41,12 +45,13 @@ def test_device_tree_structure(mirt, key):
     h.close()
 
 
+@pytest.mark.parametrize("builder", list(DEVICE_BUILDERS))
 @pytest.mark.parametrize("key", ["cornell_mixed", "soup500", "conf20k", "sphere_soup", "known_answer"])
-def test_device_tree_traces_like_the_reference(mirt, oracle, key):
+def test_device_tree_traces_like_the_reference(mirt, oracle, key, builder):
     """Traversal 0 over the device-built tree: closest hits (index and t bits) and occlusion bit-exact with the reference."""
     sc = (SCENES.get(key) or SPHERE_SCENES[key])()
     oracle.load(sc)
-    s = mirt.Scene(sc, builder="device")
+    s = mirt.Scene(sc, builder=builder)
     for unit in (False, True):
         rays = random_rays(sc, 30000, 15 + unit, unit)
         ci, ct, _ = oracle.trace(rays, normals=True)
@@ -64,26 +69,28 @@ def test_device_and_host_built_scenes_render_the_same_film(mirt):
     sc = scenes.conference_scene(20000)
     w, h = 320, 180
     out = []
-    for builder in ("host", "device"):
+    for builder in ("host", "device", "ploc"):
         s = mirt.Scene(sc, builder=builder)
         acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
         st = s.render_accum(w, h, acc.data_ptr(), spp=8, depth=6, rng_mode=1)
         assert st["traversal_used"] == 0
         out.append((acc.cpu(), st["closest_rays"], st["shadow_rays"]))
         s.close()
-    assert out[0][1:] == out[1][1:]
-    assert torch.equal(out[0][0], out[1][0])
+    for o in out[1:]:
+        assert out[0][1:] == o[1:]
+        assert torch.equal(out[0][0], o[0])
 
 
-def test_device_tree_one_million_triangles(mirt):
+@pytest.mark.parametrize("builder", list(DEVICE_BUILDERS))
+def test_device_tree_one_million_triangles(mirt, builder):
     """buddha* (1 046 530 triangles) at 1080p: 2 M primary hits of the ordered traversal over the device-built tree equal the
     reference walk's; build times of both builders are printed (pytest -s) for DESIGN.md."""
     sc = scenes.blob_scene(1024, 512, "buddha*")
     sc.camera = sc.camera.for_aspect(1920, 1080)
-    s = mirt.Scene(sc, builder="device")
+    s = mirt.Scene(sc, builder=builder)
     bt = s.build_times()
     counts, _, _ = s.own_tree()
-    print("device builder:", counts, {k: round(v, 2) for k, v in bt.items()})
+    print(builder, "builder:", counts, {k: round(v, 2) for k, v in bt.items()})
     i2, t2 = s.primary_hits(1920, 1080, traversal=2)
     i0, t0 = s.primary_hits(1920, 1080, traversal=0)
     assert (i0 == i2).all() and (t0 == t2).all(), f"{(i0 != i2).sum()} differ"
