@@ -20,7 +20,7 @@ int main(int argc, char **argv) {
     else if (a == "--spp") spp = (uint) atoi(next());
     else if (a == "--depth") depth = (uint) atoi(next());
     else if (a == "--rng") rng = (uint) atoi(next());
-    else if (a == "--device-build") device_build = 1;
+    else if (a == "--device-build") device_build = 2;
     else out = a;
   }
   std::vector<Primitive *> prims;

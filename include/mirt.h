@@ -142,13 +142,17 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
  * reference's BVH2 (flat primitive order, the tree of traversals 1 and 2 and of the near-tie replay) is always rebuilt on the
  * host bit for bit; the option selects who builds the ordered traversal's OWN tree, which is free in its topology. */
 typedef struct mirt_build_options {
-  uint32_t own_tree_builder;    /* 0: host, binned SAH (default; best traversal) | 1: device: Morton order, binary radix
-                                 * tree, bottom-up boxes, fold to 8-wide (raytracer_amd/csrc/build.hip; for scenes that
-                                 * are rebuilt every frame, the reference app's 80-frame loop apps/app.cu:24-30) */
+  uint32_t own_tree_builder;    /* 0: host, binned SAH (default)
+                                 * 1: device, Morton order + binary radix tree (fastest build)
+                                 * 2: device, PLOC: nearest-neighbour clustering in Morton order (traversal within a few
+                                 *    per cent of the host tree's, built in milliseconds; falls back to 1 if clustering
+                                 *    stalls on degenerate input)
+                                 * 1 and 2 (raytracer_amd/csrc/build.hip) are for scenes that are rebuilt every frame,
+                                 * the reference app's 80-frame loop (apps/app.cu:24-30) */
   uint32_t reserved[7];
 } mirt_build_options;
 
-/* mirt_scene_create_prims with build options (NULL: defaults, or MIRT_BUILDER=device from the environment). */
+/* mirt_scene_create_prims with build options (NULL: defaults, or MIRT_BUILDER=device|ploc from the environment). */
 int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, const uint8_t *prim_type,
                            uint32_t n_prims, const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights,
                            uint32_t n_lights, uint32_t leaf_size, const mirt_build_options *build, mirt_scene **out);

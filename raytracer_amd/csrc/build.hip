@@ -9,6 +9,7 @@
 //
 // The 96-byte node and its conservative 8-bit planes are exactly host_bvh.cpp's (Collapser8); the kernels here redo that
 // arithmetic in double, including the containment checks.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -212,13 +213,14 @@ __global__ void __launch_bounds__(BLOCK) k_refit(Refit r) {
 }
 
 // ---- PLOC (Meister & Bittner, "Parallel locally-ordered clustering for bounding volume hierarchy construction", TVCG
-// 2018): the clusters, kept in Morton order, each look for the neighbour within PLOC_RADIUS positions whose union with
+// 2018): the clusters, kept in Morton order, each look for the neighbour within `radius` positions whose union with
 // them has the smallest area; mutual nearest neighbours merge; the list is compacted (order kept) and the search repeats
 // until one cluster is left.  Bottom-up with a surface-area criterion: about the traversal cost of a binned SAH tree.
-constexpr int PLOC_RADIUS = 16;
+constexpr int PLOC_RADIUS_MAX = 64;
 
 struct Ploc {
   uint32_t m;
+  int radius;
   const uint32_t *cl_in;                                    // cluster = node reference (LEAF_BIT | sorted position, or inner id)
   const float4 *lo_in, *hi_in;                              // its box; lo.w carries the primitive count (bits)
   uint32_t *nn;
@@ -238,7 +240,8 @@ __device__ __forceinline__ float union_area(const float4 &alo, const float4 &ahi
 }
 
 __global__ void __launch_bounds__(BLOCK) k_ploc_nn(Ploc p) {
-  __shared__ float4 slo[BLOCK + 2 * PLOC_RADIUS], shi[BLOCK + 2 * PLOC_RADIUS];
+  __shared__ float4 slo[BLOCK + 2 * PLOC_RADIUS_MAX], shi[BLOCK + 2 * PLOC_RADIUS_MAX];
+  const int PLOC_RADIUS = p.radius;
   const int base = (int) (blockIdx.x * BLOCK) - PLOC_RADIUS;
   for (int t = threadIdx.x; t < BLOCK + 2 * PLOC_RADIUS; t += BLOCK) {
     const int g = base + t;
@@ -253,12 +256,13 @@ __global__ void __launch_bounds__(BLOCK) k_ploc_nn(Ploc p) {
   const float4 mlo = slo[threadIdx.x + PLOC_RADIUS], mhi = shi[threadIdx.x + PLOC_RADIUS];
   float best_a = INFINITY;
   int best = -1;
-  // increasing index, strict '<': among equal areas the lowest index wins, which guarantees a mutual pair per pass
+  // Among equal areas the pair partner i ^ 1 wins, then the lowest index.  Either way the closest pair of a pass is mutual
+  // (so every pass merges something), and a run of identical boxes pairs up (2k, 2k + 1) instead of one pair per pass.
   for (int o = -PLOC_RADIUS; o <= PLOC_RADIUS; o++) {
     const int g = i + o;
     if (o == 0 || g < 0 || g >= (int) p.m) continue;
     const float a = union_area(mlo, mhi, slo[threadIdx.x + PLOC_RADIUS + o], shi[threadIdx.x + PLOC_RADIUS + o]);
-    if (a < best_a || best < 0) {
+    if (best < 0 || a < best_a || (a == best_a && g == (i ^ 1))) {
       best_a = a;
       best = g;
     }
@@ -583,6 +587,10 @@ int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat
   BCHK(sc.get(&d_tmp, tmp_bytes));
   BCHK(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, n, 0, 63, stream));
   BCHK(hipEventRecord(ev[1], stream));
+  uint32_t h_flags = 0;
+  BCHK(hipMemcpyAsync(&h_flags, d_scene + 6, 4, hipMemcpyDeviceToHost, stream));
+  BCHK(hipStreamSynchronize(stream));
+  if (h_flags & 1) { res.error = "non-finite vertex: no quantised tree"; return 1; }
 
   // binary tree over the sorted primitives: child / range / boxes per inner node, `sorted` = leaf position -> flat primitive
   uint2 *t_child = nullptr, *t_range = nullptr;
@@ -596,8 +604,14 @@ int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat
   BCHK(sc.get(&t_parent_leaf, n));
   BCHK(sc.get(&t_nlo, n));
   BCHK(sc.get(&t_nhi, n));
-  if (method == 2) {
+  bool ploc = method == 2;
+  if (ploc) {
     Ploc pl{};
+    pl.radius = 32;                                          // measured: tools/ploc_sweep.sh
+    if (const char *e = getenv("MIRT_PLOC_RADIUS")) {
+      int v = atoi(e);
+      if (v >= 1 && v <= PLOC_RADIUS_MAX) pl.radius = v;
+    }
     uint32_t *cl_x = nullptr, *cl_y = nullptr, *d_pos_scan = nullptr, *d_m = nullptr, *leaf_pos = nullptr, *sorted2 = nullptr;
     float4 *lo_x = nullptr, *hi_x = nullptr, *lo_y = nullptr, *hi_y = nullptr;
     BCHK(sc.get(&cl_x, n));
@@ -628,7 +642,7 @@ int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat
     BCHK(sc.get(&d_scan_tmp, scan_bytes));
     uint32_t m = n, passes = 0;
     while (m > 1) {
-      if (++passes > 8192) { res.error = "PLOC did not converge"; return 1; }
+      if (++passes > 1024) { ploc = false; break; }          // degenerate input: the Morton radix tree below takes over
       const uint32_t mb = (m + BLOCK - 1) / BLOCK;
       pl.m = m;
       pl.cl_in = cl_x;
@@ -650,6 +664,8 @@ int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat
       if (m_next == 0 || m_next >= m) { res.error = "PLOC made no progress"; return -1; }
       m = m_next;
     }
+    res.passes = passes;
+    if (ploc) {
     BCHK(hipMemcpyAsync(&root_ref, cl_x, 4, hipMemcpyDeviceToHost, stream));
     Order od{n, t_child, pl.count, t_parent_inner, t_parent_leaf};
     hipLaunchKernelGGL(k_ploc_leaf_order, dim3(nb), dim3(BLOCK), 0, stream, od, vals_b, leaf_pos, sorted2);
@@ -657,8 +673,9 @@ int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat
     hipLaunchKernelGGL(k_ploc_relabel, dim3(nb), dim3(BLOCK), 0, stream, n, leaf_pos, t_child);
     BCHK(hipGetLastError());
     t_sorted = sorted2;
-    res.passes = passes;
-  } else {
+    }
+  }
+  if (!ploc) {
     Radix rt{};
     rt.keys = keys_b;
     rt.n = n;
@@ -689,12 +706,9 @@ int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat
   BCHK(sc.get(&queue_a, n));
   BCHK(sc.get(&queue_b, n));
   BCHK(sc.get(&d_next, 2));
-  uint32_t h_flags = 0;
-  BCHK(hipMemcpyAsync(&h_flags, d_scene + 6, 4, hipMemcpyDeviceToHost, stream));
   BCHK(hipStreamSynchronize(stream));                        // (root_ref of the PLOC path has arrived)
   BCHK(hipMemcpyAsync(queue_a, &root_ref, 4, hipMemcpyHostToDevice, stream));
   BCHK(hipStreamSynchronize(stream));
-  if (h_flags & 1) { res.error = "non-finite vertex: no quantised tree"; return 1; }
   Fold fd{};
   fd.n = n;
   fd.max_leaf = max_leaf;
