@@ -109,3 +109,28 @@ def test_non_finite_scene_falls_back_like_the_host_builder(mirt):
     idx1, _ = s.primary_hits(32, 32, traversal=1)
     assert (idx == idx1).all()
     s.close()
+
+
+@pytest.mark.parametrize("builder", list(DEVICE_BUILDERS))
+def test_identical_and_clustered_primitives(mirt, builder):
+    """Degenerate input: 3 000 copies of one triangle (equal Morton keys, equal merge costs everywhere: the radix tree splits
+    by index, the clustering pairs up (2k, 2k + 1)) next to 1 000 ordinary ones.  The reference puts the copies into one
+    oversized leaf (bvh.cuh:216-220); hits must still be the reference walk's, ties included (last copy wins)."""
+    sc = scenes.random_soup(4000, 9)
+    sc.pos = sc.pos.copy()
+    sc.pos[:3000] = sc.pos[0]
+    s = mirt.Scene(sc, builder=builder)
+    counts, nodes, prims = s.own_tree()
+    assert counts["builder"] == DEVICE_BUILDERS[builder] and counts["nodes"] > 0
+    _, flat = s.bvh2()
+    check_own_tree(nodes, prims[:, 9], sc.pos[flat], np.zeros(sc.n, bool), sc.n)
+    rays = random_rays(sc, 20000, 3, True)
+    c = sc.pos[0].reshape(3, 3).mean(0)
+    rays[:5000, 3:6] = c - rays[:5000, :3]                          # aimed at the stack of copies
+    rays[:5000, 3:6] /= np.linalg.norm(rays[:5000, 3:6], axis=1, keepdims=True)
+    rays[:5000, 7] = np.inf
+    i2, t2 = s.trace(rays, traversal=2)
+    i0, t0 = s.trace(rays, traversal=0)
+    assert (i0 == i2).all() and (t0 == t2).all()
+    assert (i2[:5000] >= 0).mean() > 0.5
+    s.close()
