@@ -369,8 +369,16 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
 // Queue positions are reserved once per workgroup and queue (three atomics, each on a line of its own): a slot that is
 // not finished always leaves a ray in one of the queues, so the queue counters double as the "anything left?" test and
 // as the ray statistics (the host adds them up per iteration).
+#ifndef MIRT_LOGIC_WAVES
+#define MIRT_LOGIC_WAVES 0
+#endif
+#if MIRT_LOGIC_WAVES
+#define MIRT_LOGIC_ATTR __attribute__((amdgpu_waves_per_eu(MIRT_LOGIC_WAVES)))
+#else
+#define MIRT_LOGIC_ATTR
+#endif
 template<bool MF>
-__global__ void __launch_bounds__(256) k_logic(RenderArgs a) {
+__global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
   __shared__ uint32_t wave_cnt[4][3];
   __shared__ uint32_t block_base[3], block_tot[3];
   const uint32_t tid = threadIdx.x, wave = tid >> 6;

@@ -10,9 +10,9 @@ namespace mirt {
 
 constexpr int TRACE_BLOCK = 256;
 #ifndef MIRT_LDS_STACK
-#define MIRT_LDS_STACK 12
+#define MIRT_LDS_STACK 10
 #endif
-constexpr int LDS_STACK = MIRT_LDS_STACK;        // traversal-stack entries per lane kept in LDS (8 B each): 24 KiB per workgroup
+constexpr int LDS_STACK = MIRT_LDS_STACK;        // traversal-stack entries per lane kept in LDS (8 B each): 20 KiB per workgroup: 7 workgroups per CU (12 entries, 6 workgroups: 1.3 % slower)
 constexpr int BVH2_STACK = 64;       // k_trace2 (the reference uses 32 unchecked, util/misc.cuh:19)
 
 // per-slot flag bits (RenderArgs::st[].z low byte)
