@@ -209,7 +209,9 @@ def main():
         avg_launch_ms = k_ms / max(1, launches)
         achieved = (k_rays * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
-            "metric": "Mrays/s (all bounces), conference.obj stand-in 1080p 64spp",
+            "metric": f"Mrays/s (all bounces), {args.workload.rstrip('*')}.obj stand-in {args.width}x{args.height} {args.spp}spp"
+                      if (args.workload, args.width, args.height, args.spp) != ("conference*", 1920, 1080, 64)
+                      else "Mrays/s (all bounces), conference.obj stand-in 1080p 64spp",
             "value": rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
