@@ -75,6 +75,7 @@ struct Global {
   hipEvent_t fork_ev[2][RING] = {}, join_ev[2][RING] = {};
   hipEvent_t pipe_ev[2] = {};
   bool one_pipe = false;
+  uint32_t live_16th = 4;               // MIRT_LIVE_16TH: k_logic walks the live-slot list once it is below this share of the slots
   bool blocks_forced = false;           // MIRT_BLOCKS_PER_CU given
   float table[256];
   bool table_exact = false;
@@ -123,12 +124,12 @@ struct mirt_scene {
   uint32_t ovf_depth = 0;
   uint32_t trace_threads = 0;
   // work buffers (sized per render)
-  DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2], mf_queue;
+  DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2], mf_queue, live[2];
   DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t, planes;
   size_t device_bytes() const {
     const DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                            &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0],
-                           &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue, &planes};
+                           &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue, &planes, &live[0], &live[1]};
     size_t s = 0;
     for (auto *b: all) s += b->bytes;
     return s;
@@ -136,7 +137,7 @@ struct mirt_scene {
   void release_all() {
     DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                      &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0], &redo_q[1],
-                     &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue, &planes};
+                     &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue, &planes, &live[0], &live[1]};
     for (auto *b: all) b->release();
   }
 };
@@ -182,6 +183,10 @@ int mirt_init(int device) {
   }
   if (const char *s = getenv("MIRT_SERIAL")) G.serial = atoi(s) != 0;
   if (const char *s = getenv("MIRT_ONE_PIPE")) G.one_pipe = atoi(s) != 0;
+  if (const char *s = getenv("MIRT_LIVE_16TH")) {
+    int v = atoi(s);
+    if (v >= 0 && v <= 16) G.live_16th = (uint32_t) v;
+  }
   if (const char *s = getenv("MIRT_STATIC_16TH")) {
     int v = atoi(s);
     if (v >= 0 && v <= 16) G.static_16th = (uint32_t) v;
@@ -536,7 +541,9 @@ int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
   HIPCHK(s->redo_q[0].ensure(n * 4));
   HIPCHK(s->redo_q[1].ensure(kn * 4));
   HIPCHK(s->mf_queue.ensure(n * 4));
-  HIPCHK(s->ctrl.ensure(2 * CTRL_WORDS * 4));
+  HIPCHK(s->live[0].ensure(n * 4));
+  HIPCHK(s->live[1].ensure(n * 4));
+  HIPCHK(s->ctrl.ensure(4 * CTRL_WORDS * 4));                          // 2 pipes x 2 (an iteration uses block `iteration & 1`)
   HIPCHK(s->ray_stats.ensure(2 * 16 * 8));
   return MIRT_OK;
 }
@@ -559,9 +566,9 @@ TraceArgs common_args(mirt_scene *s, uint32_t traversal) {
   t.ovf_depth = s->ovf_depth;
   return t;
 }
-TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal, int pipe = 0, size_t off = 0) {
+TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal, int pipe = 0, size_t off = 0, int par = 0) {
   TraceArgs t = common_args(s, traversal);
-  uint32_t *ctrl = s->ctrl.as<uint32_t>() + (size_t) pipe * CTRL_WORDS;
+  uint32_t *ctrl = s->ctrl.as<uint32_t>() + (size_t) (2 * pipe + par) * CTRL_WORDS;
   unsigned long long *rs = s->ray_stats.as<unsigned long long>() + (size_t) pipe * 16;
   t.ray_o = s->ray_o.as<float4>() + off;
   t.ray_d = s->ray_d.as<float4>() + off;
@@ -580,9 +587,9 @@ TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal, int 
   t.count_stat = rs + 4;
   return t;
 }
-TraceArgs shadow_args(mirt_scene *s, uint32_t traversal, int pipe = 0, size_t koff = 0) {
+TraceArgs shadow_args(mirt_scene *s, uint32_t traversal, int pipe = 0, size_t koff = 0, int par = 0) {
   TraceArgs t = common_args(s, traversal);
-  uint32_t *ctrl = s->ctrl.as<uint32_t>() + (size_t) pipe * CTRL_WORDS;
+  uint32_t *ctrl = s->ctrl.as<uint32_t>() + (size_t) (2 * pipe + par) * CTRL_WORDS;
   unsigned long long *rs = s->ray_stats.as<unsigned long long>() + (size_t) pipe * 16;
   t.ray_o = s->sh_o.as<float4>() + koff;
   t.ray_d = s->sh_d.as<float4>() + koff;
@@ -690,6 +697,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   a.out_accum = via_planes ? s->planes.as<float4>() : (float4 *) accum_dev;
   a.tri_nrm = s->tri_nrm.as<float4>(); a.mats = s->mats.as<float4>(); a.lights = s->lights.as<float>();
   a.mf_queue = s->mf_queue.as<uint32_t>(); a.mf_count = ctrl + CTRL_MF;
+  a.live_16th = G.live_16th;
 
   const bool profile = stats && (o.flags & 1u);
   const bool profile_closest = stats && (o.flags & 9u);                  // bit 3: time the closest-hit launches only
@@ -705,7 +713,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   if (!accumulate) HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
   if (via_planes) HIPCHK(hipMemsetAsync(s->planes.p, 0, (size_t) streams * w * h * 16, G.stream));
   HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, 2 * 128, G.stream));
-  HIPCHK(hipMemsetAsync(s->ctrl.p, 0, 2 * CTRL_WORDS * 4, G.stream));
+  HIPCHK(hipMemsetAsync(s->ctrl.p, 0, 4 * CTRL_WORDS * 4, G.stream));
   HIPCHK(hipEventRecord(evA, G.stream));
 
   // Pipes: with at least two sample streams the slots are split into two halves that run as independent wavefront loops
@@ -713,10 +721,12 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   const int n_pipes = (streams >= 2 && !G.serial && !G.one_pipe && part.n_slots) ? 2 : 1;
   // with two pipes four persistent launches share the GPU: 4 workgroups per CU each measured best (tools/sweep_env.sh)
   const uint32_t pipe_blocks = (n_pipes == 2 && !G.blocks_forced) ? 4u : 0u;
+  // Every pipe has two control blocks and two live-slot lists; iteration i counts into block i & 1 and reads the list the
+  // iteration before it wrote (so clearing a block never races with a reader of the previous one).
   struct Pipe {
-    RenderArgs a;
-    TraceArgs tc, ts;
-    uint32_t *ctrl;
+    RenderArgs a[2];
+    TraceArgs tc[2], ts[2];
+    uint32_t *ctrl[2];
     uint64_t it = 0;
     bool done = false;
   } pipe[2];
@@ -725,19 +735,25 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     const uint32_t s_count = n_pipes == 2 ? (p == 0 ? streams / 2 : streams - streams / 2) : streams;
     const size_t off = (size_t) s_first * part.n_slots, koff = off * (K ? K : 1);
     Pipe &pp = pipe[p];
-    pp.ctrl = ctrl + (size_t) p * CTRL_WORDS;
-    pp.a = a;
-    pp.a.n_slots = part.n_slots * s_count;
-    pp.a.stream_first = s_first;
-    pp.a.st += off; pp.a.mask += off; pp.a.total += off; pp.a.accum += off; pp.a.dmask += off;
-    pp.a.ray_o += off; pp.a.ray_d += off; pp.a.hit += off;
-    pp.a.sh_o += koff; pp.a.sh_d += koff; pp.a.sh_c += koff; pp.a.sh_occ += koff;
-    pp.a.ext_queue += off; pp.a.sh_queue += koff; pp.a.mf_queue += off;
-    pp.a.qcount = pp.ctrl + CTRL_QCOUNT;
-    pp.a.mf_count = pp.ctrl + CTRL_MF;
-    pp.a.ray_stats = a.ray_stats + (size_t) p * 16;
-    pp.tc = closest_args(s, pp.a.n_slots, o.traversal, p, off);
-    pp.ts = shadow_args(s, o.traversal, p, koff);
+    for (int par = 0; par < 2; par++) {
+      RenderArgs &pa = pp.a[par];
+      pp.ctrl[par] = ctrl + (size_t) (2 * p + par) * CTRL_WORDS;
+      pa = a;
+      pa.n_slots = part.n_slots * s_count;
+      pa.stream_first = s_first;
+      pa.st += off; pa.mask += off; pa.total += off; pa.accum += off; pa.dmask += off;
+      pa.ray_o += off; pa.ray_d += off; pa.hit += off;
+      pa.sh_o += koff; pa.sh_d += koff; pa.sh_c += koff; pa.sh_occ += koff;
+      pa.ext_queue += off; pa.sh_queue += koff; pa.mf_queue += off;
+      pa.qcount = pp.ctrl[par] + CTRL_QCOUNT;
+      pa.mf_count = pp.ctrl[par] + CTRL_MF;
+      pa.ray_stats = a.ray_stats + (size_t) p * 16;
+      pa.live_out = s->live[par].as<uint32_t>() + off;
+      pa.live_in = s->live[par ^ 1].as<uint32_t>() + off;
+      pa.live_in_count = ctrl + (size_t) (2 * p + (par ^ 1)) * CTRL_WORDS + CTRL_QCOUNT + QC_LIVE;
+      pp.tc[par] = closest_args(s, pa.n_slots, o.traversal, p, off, par);
+      pp.ts[par] = shadow_args(s, o.traversal, p, koff, par);
+    }
   }
   uint32_t iters = 0;
   uint64_t n_camera = 0, n_bounced = 0, n_shadow_rays = 0;
@@ -746,7 +762,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
       HIPCHK(hipEventRecord(G.pipe_ev[0], G.stream));
       HIPCHK(hipStreamWaitEvent(G.pstream[1], G.pipe_ev[0], 0));
     }
-    for (int p = 0; p < n_pipes; p++) HIPCHK(launch_init(pipe[p].a, G.pstream[p]));
+    for (int p = 0; p < n_pipes; p++) HIPCHK(launch_init(pipe[p].a[0], G.pstream[p]));
     const uint64_t max_iters = (uint64_t) a.spp * ((uint64_t) a.max_depth + 3) + 8;
     bool all_done = false;
     while (!all_done) {
@@ -762,7 +778,10 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
           (void) hipDeviceSynchronize();
           return fail(MIRT_E_DEVICE, "wavefront loop did not terminate");
         }
-        HIPCHK(hipMemsetAsync(pp.ctrl, 0, CTRL_ERR * 4, main));          // queue counters, work heads, redo counters
+        const int par = (int) (it & 1);
+        RenderArgs la = pp.a[par];
+        if (it == 0) la.live_in = nullptr;                               // no list yet: all slots
+        HIPCHK(hipMemsetAsync(pp.ctrl[par], 0, CTRL_ERR * 4, main));     // queue counters, work heads, redo counters
         Timed tl{0, nullptr, nullptr};
         if (profile) {
           tl.a = G.pool_next();
@@ -770,14 +789,14 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
           if (!tl.a || !tl.b) return fail(MIRT_E_DEVICE, "could not create timing events");
           HIPCHK(hipEventRecord(tl.a, main));
         }
-        HIPCHK(launch_logic(pp.a, false, main));
-        if (s->has_microfacet) HIPCHK(launch_logic(pp.a, true, main));
+        HIPCHK(launch_logic(la, false, main));
+        if (s->has_microfacet) HIPCHK(launch_logic(la, true, main));
         if (profile) {
           HIPCHK(hipEventRecord(tl.b, main));
           timed.push_back(tl);
         }
         const int slot = (int) (it % RING);
-        HIPCHK(hipMemcpyAsync(hcounts + slot * QC_WORDS, pp.ctrl + CTRL_QCOUNT, QC_WORDS * 4, hipMemcpyDeviceToHost, main));
+        HIPCHK(hipMemcpyAsync(hcounts + slot * QC_WORDS, pp.ctrl[par] + CTRL_QCOUNT, QC_WORDS * 4, hipMemcpyDeviceToHost, main));
         HIPCHK(hipEventRecord(G.ring_ev[p][slot], main));
         // The two traversals of an iteration are independent: the shadow rays go to the side stream, so the tail of one
         // launch (a few long rays, the GPU mostly idle) is filled by the other.  MIRT_SERIAL=1 keeps one stream.
@@ -785,14 +804,14 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
         if (fork) {
           HIPCHK(hipEventRecord(G.fork_ev[p][slot], main));
           HIPCHK(hipStreamWaitEvent(side, G.fork_ev[p][slot], 0));
-          rc = run_trace(s, pp.ts, true, o.traversal, profile ? &timed : nullptr, counting, side, pipe_blocks);
+          rc = run_trace(s, pp.ts[par], true, o.traversal, profile ? &timed : nullptr, counting, side, pipe_blocks);
           if (rc) return rc;
           HIPCHK(hipEventRecord(G.join_ev[p][slot], side));
         }
-        rc = run_trace(s, pp.tc, false, o.traversal, profile_closest ? &timed : nullptr, counting, main, pipe_blocks);
+        rc = run_trace(s, pp.tc[par], false, o.traversal, profile_closest ? &timed : nullptr, counting, main, pipe_blocks);
         if (rc) return rc;
         if (K && !fork) {
-          rc = run_trace(s, pp.ts, true, o.traversal, profile ? &timed : nullptr, counting, main, pipe_blocks);
+          rc = run_trace(s, pp.ts[par], true, o.traversal, profile ? &timed : nullptr, counting, main, pipe_blocks);
           if (rc) return rc;
         }
         if (fork) HIPCHK(hipStreamWaitEvent(main, G.join_ev[p][slot], 0));
@@ -819,10 +838,12 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     HIPCHK(launch_sum_planes(s->planes.as<float4>(), streams, w * h, (float4 *) accum_dev, accumulate ? 1 : 0, G.stream));
   HIPCHK(hipEventRecord(evB, G.stream));
   HIPCHK(hipEventSynchronize(evB));
-  uint32_t err = 0, err1 = 0;
-  HIPCHK(hipMemcpy(&err, ctrl + CTRL_ERR, 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(&err1, ctrl + CTRL_WORDS + CTRL_ERR, 4, hipMemcpyDeviceToHost));
-  err |= err1;
+  uint32_t err = 0;
+  for (int b = 0; b < 4; b++) {
+    uint32_t e1 = 0;
+    HIPCHK(hipMemcpy(&e1, ctrl + (size_t) b * CTRL_WORDS + CTRL_ERR, 4, hipMemcpyDeviceToHost));
+    err |= e1;
+  }
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, evA, evB));
   (void) hipEventDestroy(evA);

@@ -379,10 +379,11 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
 #endif
 template<bool MF>
 __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
-  __shared__ uint32_t wave_cnt[4][3];
-  __shared__ uint32_t block_base[3], block_tot[3];
+  __shared__ uint32_t wave_cnt[4][4];
+  __shared__ uint32_t block_base[4], block_tot[4];
   const uint32_t tid = threadIdx.x, wave = tid >> 6;
-  const uint32_t n = MF ? *a.mf_count : a.n_slots;
+  const bool listed = !MF && a.live_in != nullptr && (uint64_t) *a.live_in_count * 16u <= (uint64_t) a.n_slots * a.live_16th;
+  const uint32_t n = MF ? *a.mf_count : (listed ? *a.live_in_count : a.n_slots);
   const uint32_t K = a.n_lights * a.spl;
   for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
     const uint32_t i = base + tid;
@@ -390,26 +391,29 @@ __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
     Emit em;
     em.ext = 0; em.nsh = 0;
     if (i < n) {
-      s = MF ? a.mf_queue[i] : i;
+      s = MF ? a.mf_queue[i] : (listed ? a.live_in[i] : i);
       const uint4 st = a.st[s];
       if (MF || !(st.z & F_DONE)) logic_slot<MF>(a, s, st, em);
     }
-    const uint64_t m0 = __ballot(em.ext == 1), m1 = __ballot(em.ext == 2), m2 = __ballot(em.nsh != 0);
+    // (a slot that is not finished has just emitted something; one handed to the MICROFACET kernel is listed by that one)
+    const uint64_t m0 = __ballot(em.ext == 1), m1 = __ballot(em.ext == 2), m2 = __ballot(em.nsh != 0),
+                   m3 = __ballot(em.ext != 0 || em.nsh != 0);
     if ((tid & 63) == 0) {
       wave_cnt[wave][0] = (uint32_t) __popcll(m0);
       wave_cnt[wave][1] = (uint32_t) __popcll(m1);
       wave_cnt[wave][2] = (uint32_t) __popcll(m2);
+      wave_cnt[wave][3] = (uint32_t) __popcll(m3);
     }
     __syncthreads();
-    if (tid < 3) {
+    if (tid < 4) {
       const uint32_t tot = wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
       block_tot[tid] = tot;
       block_base[tid] = tot ? atomicAdd(a.qcount + CTR_STRIDE * tid, tid == 2 ? tot * K : tot) : 0u;
     }
     __syncthreads();
-    uint32_t off[3] = {0, 0, 0};
+    uint32_t off[4] = {0, 0, 0, 0};
     for (uint32_t w = 0; w < wave; w++) {
-      off[0] += wave_cnt[w][0]; off[1] += wave_cnt[w][1]; off[2] += wave_cnt[w][2];
+      off[0] += wave_cnt[w][0]; off[1] += wave_cnt[w][1]; off[2] += wave_cnt[w][2]; off[3] += wave_cnt[w][3];
     }
     if (em.ext == 1) a.ext_queue[block_base[0] + off[0] + lane_rank(m0)] = s;                     // camera rays: front
     if (em.ext == 2) a.ext_queue[a.n_slots - 1 - (block_base[1] + off[1] + lane_rank(m1))] = s;   // bounced rays: back
@@ -418,6 +422,7 @@ __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
       const uint32_t p = block_base[2] + off[2] + lane_rank(m2);
       for (uint32_t k = 0; k < K; k++) a.sh_queue[p + k * block_tot[2]] = k * a.n_slots + s;
     }
+    if (em.ext != 0 || em.nsh != 0) a.live_out[block_base[3] + off[3] + lane_rank(m3)] = s;
     __syncthreads();
   }
 }

@@ -21,7 +21,7 @@ enum : uint32_t { F_DONE = 1, F_HAS_RAY = 2, F_PENDING = 4, F_AHEAD = 8 };
 // 128-byte line of its own: same-address atomics retire at ~11 ns each on MI355X (tools/micro/atomic_rate.hip) and
 // counters sharing a line queue up behind each other.
 constexpr int CTR_STRIDE = 32;
-enum : int { QC_EXT_FRONT = 0, QC_EXT_BACK = CTR_STRIDE, QC_SHADOW = 2 * CTR_STRIDE, QC_WORDS = 3 * CTR_STRIDE };
+enum : int { QC_EXT_FRONT = 0, QC_EXT_BACK = CTR_STRIDE, QC_SHADOW = 2 * CTR_STRIDE, QC_LIVE = 3 * CTR_STRIDE, QC_WORDS = 4 * CTR_STRIDE };
 constexpr int WORK_PARTS = 8;        // a trace launch splits its queue into this many ranges, one fetch counter each
 
 struct RenderArgs {
@@ -47,6 +47,12 @@ struct RenderArgs {
   const float4 *tri_nrm;                  // 3 float4 per triangle: n1 n2 n3, material, original index
   const float4 *mats;                     // 3 float4 per material: mirt_bsdf (9 dwords) padded to 48 B
   uint32_t *mf_queue, *mf_count;          // slots whose hit material is MICROFACET: shaded by k_logic<true>
+  // Slots that are still rendering after this launch are appended to live_out (count: qcount[QC_LIVE]); the next launch
+  // walks the previous list instead of all slots once it covers less than half of them (the tail of a frame, where a
+  // wave would otherwise run the whole slot function for one or two lanes).  live_in == NULL: first iteration.
+  const uint32_t *live_in, *live_in_count;
+  uint32_t *live_out;
+  uint32_t live_16th;                     // the list is used when it holds at most live_16th / 16 of the slots
   const float *lights;                    // 17 dwords per light (mirt_light)
 };
 
