@@ -80,6 +80,9 @@ struct Global {
   float table[256];
   bool table_exact = false;
   DevBuf d_table, d_rgb;
+  uint32_t *h_film = nullptr;            // pinned: the packed film on its way to the caller
+  size_t h_film_words = 0;
+  hipEvent_t film_ev[8] = {};
   uint32_t *h_counts = nullptr;          // pinned: 2 pipes x RING x QC_WORDS
   hipEvent_t ring_ev[2][RING] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -174,6 +177,7 @@ int mirt_init(int device) {
   HIPCHK(G.d_table.ensure(sizeof(G.table)));
   HIPCHK(hipMemcpy(G.d_table.p, G.table, sizeof(G.table), hipMemcpyHostToDevice));
   HIPCHK(hipHostMalloc((void **) &G.h_counts, 2 * RING * QC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  for (auto &e: G.film_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(hipEventCreate(&G.ev0));
   HIPCHK(hipEventCreate(&G.ev1));
   G.blocks_per_cu = trace4_blocks_per_cu();
@@ -216,6 +220,8 @@ void mirt_shutdown(void) {
   if (G.ev0) (void) hipEventDestroy(G.ev0);
   if (G.ev1) (void) hipEventDestroy(G.ev1);
   if (G.h_counts) (void) hipHostFree(G.h_counts);
+  if (G.h_film) (void) hipHostFree(G.h_film);
+  for (auto e: G.film_ev) if (e) (void) hipEventDestroy(e);
   for (auto e: G.pool) (void) hipEventDestroy(e);
   G.d_table.release();
   G.d_rgb.release();
@@ -839,10 +845,10 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   HIPCHK(hipEventRecord(evB, G.stream));
   HIPCHK(hipEventSynchronize(evB));
   uint32_t err = 0;
-  for (int b = 0; b < 4; b++) {
-    uint32_t e1 = 0;
-    HIPCHK(hipMemcpy(&e1, ctrl + (size_t) b * CTRL_WORDS + CTRL_ERR, 4, hipMemcpyDeviceToHost));
-    err |= e1;
+  {
+    std::vector<uint32_t> blocks((size_t) 4 * CTRL_WORDS);               // one copy for the four error flags
+    HIPCHK(hipMemcpy(blocks.data(), ctrl, blocks.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < 4; b++) err |= blocks[(size_t) b * CTRL_WORDS + CTRL_ERR];
   }
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, evA, evB));
@@ -899,11 +905,44 @@ int mirt_tonemap(const void *accum_dev, uint32_t width, uint32_t height, int32_t
   if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
   if (!accum_dev || !rgb_out || !width || !height) return fail(MIRT_E_ARG, "null / empty argument");
   const size_t n = (size_t) width * height;
-  HIPCHK(G.d_rgb.ensure(n * 12));                                        // kept between calls
-  hipError_t e = launch_tonemap(accum_dev, (uint32_t) n, G.d_table.as<float>(), G.d_rgb.as<int32_t>(), G.stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(rgb_out, G.d_rgb.p, n * 12, hipMemcpyDeviceToHost, G.stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(G.stream);
-  if (e != hipSuccess) return fail(MIRT_E_DEVICE, std::string("tonemap: ") + hipGetErrorString(e));
+  HIPCHK(G.d_rgb.ensure(n * 4));                                         // kept between calls
+  if (G.h_film_words < n) {                                              // pinned staging, kept between calls
+    if (G.h_film) (void) hipHostFree(G.h_film);
+    G.h_film = nullptr;
+    G.h_film_words = 0;
+    HIPCHK(hipHostMalloc((void **) &G.h_film, n * 4, hipHostMallocDefault));
+    G.h_film_words = n;
+  }
+  // one packed word per pixel crosses PCIe, in a few pieces; host threads widen each piece to three ints as it lands
+  constexpr int PIECES = 8;
+  hipError_t e = launch_tonemap(accum_dev, (uint32_t) n, G.d_table.as<float>(), G.d_rgb.as<uint32_t>(), G.stream);
+  size_t cut[PIECES + 1];
+  for (int k = 0; k <= PIECES; k++) cut[k] = n * (size_t) k / PIECES;
+  for (int k = 0; k < PIECES && e == hipSuccess; k++) {
+    if (cut[k + 1] > cut[k])
+      e = hipMemcpyAsync(G.h_film + cut[k], G.d_rgb.as<uint32_t>() + cut[k], (cut[k + 1] - cut[k]) * 4, hipMemcpyDeviceToHost,
+                         G.stream);
+    if (e == hipSuccess) e = hipEventRecord(G.film_ev[k], G.stream);
+  }
+  if (e != hipSuccess) {
+    (void) hipStreamSynchronize(G.stream);
+    return fail(MIRT_E_DEVICE, std::string("tonemap: ") + hipGetErrorString(e));
+  }
+  std::atomic<int> bad{0};
+  parallel_for(PIECES, [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; k++) {
+      if (hipEventSynchronize(G.film_ev[k]) != hipSuccess) { bad.store(1); continue; }
+      const uint32_t *src = G.h_film;
+      for (size_t i = cut[k]; i < cut[k + 1]; i++) {
+        const uint32_t v = src[i];
+        rgb_out[3 * i] = (int32_t) (v & 0xFFu);
+        rgb_out[3 * i + 1] = (int32_t) ((v >> 8) & 0xFFu);
+        rgb_out[3 * i + 2] = (int32_t) ((v >> 16) & 0xFFu);
+      }
+    }
+  }, 1);
+  e = hipStreamSynchronize(G.stream);
+  if (e != hipSuccess || bad.load()) return fail(MIRT_E_DEVICE, std::string("tonemap: ") + hipGetErrorString(e));
   return MIRT_OK;
 }
 

@@ -1199,7 +1199,9 @@ __global__ void k_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n
 }
 
 // ============================================================================================ film
-__global__ void k_tonemap(const float4 *accum, uint32_t n, const float *table, int32_t *rgb) {
+// One packed word per pixel (r | g << 8 | b << 16): the film's values are 0..255, and a third of the bytes cross PCIe;
+// the host widens them to the reference's three ints per pixel (image.cuh:10-13).
+__global__ void k_tonemap(const float4 *accum, uint32_t n, const float *table, uint32_t *rgb) {
   __shared__ float T[256];
   T[threadIdx.x & 255] = table[threadIdx.x & 255];
   __syncthreads();
@@ -1208,6 +1210,7 @@ __global__ void k_tonemap(const float4 *accum, uint32_t n, const float *table, i
   const float4 v = accum[i];
   const float rc = 1.0f / v.w;                    // color /= i - 1  (raytracer.cuh:124; Vector3f.cuh:133-135)
   const float c3[3] = {v.x * rc, v.y * rc, v.z * rc};
+  uint32_t packed = 0;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const float c = c3[k];
@@ -1222,8 +1225,9 @@ __global__ void k_tonemap(const float4 *accum, uint32_t n, const float *table, i
       }
       out = lo;
     }
-    rgb[3 * (size_t) i + k] = out;
+    packed |= (uint32_t) out << (8 * k);
   }
+  rgb[i] = packed;
 }
 
 // ============================================================================================ launchers
@@ -1265,7 +1269,7 @@ hipError_t launch_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n
   LAUNCH_CHECK();
   return hipSuccess;
 }
-hipError_t launch_tonemap(const void *accum, uint32_t n, const float *table, int32_t *rgb, hipStream_t st) {
+hipError_t launch_tonemap(const void *accum, uint32_t n, const float *table, uint32_t *rgb, hipStream_t st) {
   k_tonemap<<<(n + 255) / 256, 256, 0, st>>>((const float4 *) accum, n, table, rgb);
   LAUNCH_CHECK();
   return hipSuccess;

@@ -91,7 +91,7 @@ hipError_t launch_probe_primary(const RenderArgs &a, hipStream_t st);
 hipError_t launch_gather_primary(const RenderArgs &a, int32_t *idx, uint32_t *tb, hipStream_t st);
 hipError_t launch_iota(uint32_t *q, uint32_t n, hipStream_t st);
 hipError_t launch_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n, float4 *out, int add_to_out, hipStream_t st);
-hipError_t launch_tonemap(const void *accum, uint32_t n, const float *table, int32_t *rgb, hipStream_t st);
+hipError_t launch_tonemap(const void *accum, uint32_t n, const float *table, uint32_t *rgb /* r | g << 8 | b << 16 */, hipStream_t st);
 hipError_t launch_trace(const TraceArgs &a, bool any, uint32_t traversal, uint32_t grid_blocks, hipStream_t st);
 size_t trace4_lds_bytes();
 int trace4_blocks_per_cu();
