@@ -733,8 +733,8 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     RenderArgs a[2];
     TraceArgs tc[2], ts[2];
     uint32_t *ctrl[2];
-    uint64_t it = 0;
-    bool done = false;
+    uint64_t it = 0, accounted = 0;
+    bool done = false, tail = false;
   } pipe[2];
   for (int p = 0; p < n_pipes; p++) {
     const uint32_t s_first = n_pipes == 2 ? (p == 0 ? 0 : streams / 2) : 0;
@@ -822,8 +822,13 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
         }
         if (fork) HIPCHK(hipStreamWaitEvent(main, G.join_ev[p][slot], 0));
         if (p == 0) iters++;
-        if (it + 1 >= RING - 1) {                                        // look at the counters of RING-2 iterations ago
-          const uint64_t old = it + 1 - (RING - 1);
+        // The host runs two iterations ahead of the counters it has seen, so that both pipes always have work queued; in
+        // the tail of a frame (few rays left: launches of a few microseconds, nothing to keep fed) it looks at the counters
+        // of the iteration it has just issued - they arrive as soon as k_logic has run - and stops without issuing the
+        // two or three empty iterations the lag would cost.
+        const uint64_t upto = pp.tail ? it + 1 : (it + 1 >= RING - 1 ? it + 1 - (RING - 2) : 0);   // account iterations < upto
+        while (pp.accounted < upto && !pp.done) {
+          const uint64_t old = pp.accounted++;
           const uint32_t *hc = hcounts + (old % RING) * QC_WORDS;
           HIPCHK(hipEventSynchronize(G.ring_ev[p][old % RING]));
           // a slot that is not finished leaves a ray in one of the queues: empty queues = this half is complete (and
@@ -831,7 +836,9 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
           n_camera += hc[QC_EXT_FRONT];
           n_bounced += hc[QC_EXT_BACK];
           n_shadow_rays += hc[QC_SHADOW];
-          if (hc[QC_EXT_FRONT] + hc[QC_EXT_BACK] + hc[QC_SHADOW] == 0) pp.done = true;
+          const uint32_t in_flight = hc[QC_EXT_FRONT] + hc[QC_EXT_BACK] + hc[QC_SHADOW];
+          if (in_flight == 0) pp.done = true;
+          if (in_flight < pp.a[0].n_slots / 32u) pp.tail = true;
         }
       }
     }
