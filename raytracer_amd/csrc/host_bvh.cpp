@@ -394,7 +394,7 @@ struct SahBuilder {
   const float *pos;                       // primitives in FLAT order, 9 floats each
   const uint8_t *ptype = nullptr;
   std::vector<Box> pbox;
-  std::vector<float> cent;
+  std::vector<float> cent, parea;
   std::vector<uint32_t> order;
   Pool<Node2> &out;
   std::vector<uint32_t> &perm;            // = order when the build is done (a leaf's primitives are its range of `order`)
@@ -406,14 +406,18 @@ struct SahBuilder {
 
   SahBuilder(Pool<Node2> &o, std::vector<uint32_t> &p) : out(o), perm(p) {}
 
+  // plain compare-and-select (one minss / maxss; std::fmin is a libm call that costs more than the rest of the loop): every
+  // operand is finite, prepare() refuses anything else
+  static float lo_of(float a, float b) { return b < a ? b : a; }
+  static float hi_of(float a, float b) { return a < b ? b : a; }
   static float area(const Box &b) {
     float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
     return dx * dy + dy * dz + dz * dx;
   }
   static void grow(Box &a, const Box &b) {
     for (int k = 0; k < 3; k++) {
-      a.lo[k] = std::fmin(a.lo[k], b.lo[k]);
-      a.hi[k] = std::fmax(a.hi[k], b.hi[k]);
+      a.lo[k] = lo_of(a.lo[k], b.lo[k]);
+      a.hi[k] = hi_of(a.hi[k], b.hi[k]);
     }
   }
   static Box empty() {
@@ -428,9 +432,11 @@ struct SahBuilder {
   void prepare(uint32_t n) {
     pbox.resize(n);
     cent.resize(3 * (size_t) n);
+    parea.resize(n);
     order.resize(n);
     out.reserve(2 * (size_t) n);
     fork_depth = fork_levels();
+    std::atomic<bool> bad{false};
     parallel_for(n, [&](size_t i0, size_t i1) {
     for (size_t i = i0; i < i1; i++) {
       const float *p = pos + 9 * (size_t) i;
@@ -444,25 +450,35 @@ struct SahBuilder {
       } else {
         for (int v = 0; v < 3; v++)
           for (int k = 0; k < 3; k++) {
-            b.lo[k] = std::fmin(b.lo[k], p[3 * v + k]);
-            b.hi[k] = std::fmax(b.hi[k], p[3 * v + k]);
+            b.lo[k] = lo_of(b.lo[k], p[3 * v + k]);
+            b.hi[k] = hi_of(b.hi[k], p[3 * v + k]);
           }
       }
       pbox[i] = b;
       for (int k = 0; k < 3; k++) cent[3 * (size_t) i + k] = 0.5f * (b.lo[k] + b.hi[k]);
+      parea[i] = area(b);
       order[i] = (uint32_t) i;
+      bool finite = std::isfinite(parea[i]);
+      const int used = (ptype && ptype[i] == 1) ? 4 : 9;     // a sphere's record: centre, radius, 5 unused
+      for (int k = 0; k < used; k++) finite = finite && std::isfinite(p[k]);
+      for (int k = 0; k < 3; k++)
+        finite = finite && std::isfinite(b.lo[k]) && std::isfinite(b.hi[k]) && std::isfinite(cent[3 * (size_t) i + k]);
+      if (!finite) bad.store(true, std::memory_order_relaxed);
     }
     });
+    if (bad.load()) throw std::runtime_error("non-finite vertex: no quantised tree");
   }
 
   uint32_t build(uint32_t s, uint32_t e, int depth = 0) {
     Box bb = empty(), cb = empty();
+    float max_area = 0.f;                                  // of a single primitive's box
     for (uint32_t i = s; i < e; i++) {
       grow(bb, pbox[order[i]]);
+      max_area = hi_of(max_area, parea[order[i]]);
       for (int k = 0; k < 3; k++) {
         float c = cent[3 * (size_t) order[i] + k];
-        cb.lo[k] = std::fmin(cb.lo[k], c);
-        cb.hi[k] = std::fmax(cb.hi[k], c);
+        cb.lo[k] = lo_of(cb.lo[k], c);
+        cb.hi[k] = hi_of(cb.hi[k], c);
       }
     }
     const uint32_t id = out.take();
@@ -475,11 +491,11 @@ struct SahBuilder {
     }
     // Primitives that span most of the node (a room's walls around its furniture) would inflate whichever half they fall
     // into: set them aside as one child of this node, the rest as the other.
-    if (peel > 0.f && n > max_leaf) {
+    if (peel > 0.f && n > max_leaf && max_area > peel * area(bb)) {
       const float limit = peel * area(bb);
       uint32_t i = s, j = e;
       while (i < j) {
-        if (area(pbox[order[i]]) > limit) i++;
+        if (parea[order[i]] > limit) i++;
         else std::swap(order[i], order[--j]);
       }
       const uint32_t big = i - s;
@@ -495,32 +511,43 @@ struct SahBuilder {
     // binned SAH over the three axes
     int best_axis = -1, best_bin = -1;
     float best_cost = std::numeric_limits<float>::infinity();
+    Box bins[3][BINS];
+    uint32_t cnt[3][BINS];
+    float lo3[3], scale3[3];
+    bool use[3];
     for (int ax = 0; ax < 3; ax++) {
-      const float lo = cb.lo[ax], ext = cb.hi[ax] - cb.lo[ax];
-      if (!(ext > 0)) continue;
-      Box bins[BINS];
-      uint32_t cnt[BINS];
-      for (int b = 0; b < BINS; b++) { bins[b] = empty(); cnt[b] = 0; }
-      const float scale = BINS / ext;
-      for (uint32_t i = s; i < e; i++) {
-        int b = (int) ((cent[3 * (size_t) order[i] + ax] - lo) * scale);
-        b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-        grow(bins[b], pbox[order[i]]);
-        cnt[b]++;
+      const float ext = cb.hi[ax] - cb.lo[ax];
+      use[ax] = ext > 0;
+      lo3[ax] = cb.lo[ax];
+      scale3[ax] = use[ax] ? BINS / ext : 0.f;
+      for (int k = 0; k < BINS; k++) { bins[ax][k] = empty(); cnt[ax][k] = 0; }
+    }
+    for (uint32_t i = s; i < e; i++) {                     // one pass over the primitives fills the bins of all three axes
+      const uint32_t pi = order[i];
+      const Box &pb = pbox[pi];
+      for (int ax = 0; ax < 3; ax++) {
+        if (!use[ax]) continue;
+        int k = (int) ((cent[3 * (size_t) pi + ax] - lo3[ax]) * scale3[ax]);
+        k = k < 0 ? 0 : (k >= BINS ? BINS - 1 : k);
+        grow(bins[ax][k], pb);
+        cnt[ax][k]++;
       }
+    }
+    for (int ax = 0; ax < 3; ax++) {
+      if (!use[ax]) continue;
       float ra[BINS];
       uint32_t rn[BINS];
       Box acc = empty();
       uint32_t c = 0;
-      for (int b = BINS - 1; b > 0; b--) { grow(acc, bins[b]); c += cnt[b]; ra[b] = area(acc); rn[b] = c; }
+      for (int k = BINS - 1; k > 0; k--) { grow(acc, bins[ax][k]); c += cnt[ax][k]; ra[k] = area(acc); rn[k] = c; }
       acc = empty();
       c = 0;
-      for (int b = 0; b < BINS - 1; b++) {
-        grow(acc, bins[b]);
-        c += cnt[b];
-        if (c == 0 || rn[b + 1] == 0) continue;
-        float cost = area(acc) * (float) c + ra[b + 1] * (float) rn[b + 1];
-        if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; }
+      for (int k = 0; k < BINS - 1; k++) {
+        grow(acc, bins[ax][k]);
+        c += cnt[ax][k];
+        if (c == 0 || rn[k + 1] == 0) continue;
+        float cost = area(acc) * (float) c + ra[k + 1] * (float) rn[k + 1];
+        if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = k; }
       }
     }
     uint32_t mid;
