@@ -178,3 +178,17 @@ def test_errors_are_loud_without_gpu_or_init():
     assert e.value.code == -3                                             # MIRT_E_STATE: not initialised
     assert lib.mirt_save_bmp(None, None, 0, 0) == -1
     assert lib.mirt_bvh_build_host(None, 0, 4, None, None, None, None) == -1
+
+
+def test_threaded_builders_do_not_depend_on_the_thread_count(monkeypatch):
+    """The host builders hand the halves of large ranges to threads (host_bvh.cpp): the reference's BVH2, its flat order and
+    the traversal's own tree must come out the same on 1, 3 and 16 threads."""
+    sc = scenes.blob_scene(192, 96)                     # 36 k triangles: above the size at which ranges are forked
+    assert sc.n >= 16384
+    out = []
+    for t in ("1", "3", "16"):
+        monkeypatch.setenv("MIRT_BUILD_THREADS", t)
+        out.append(capi.bvh_build_host(sc.pos, 4, sc.ptype))
+    for b in out[1:]:
+        for key in ("nodes2", "flat", "nodes4", "nodes8q", "fast_to_flat"):
+            assert (b[key] == out[0][key]).all(), key
