@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--split", action="store_true", help="add the per-kernel time split of one extra frame to the roofline object")
     ap.add_argument("--builder", default=None, choices=["host", "device", "ploc"],
                     help="who builds the ordered traversal's own tree (default: the library's, host binned SAH)")
+    ap.add_argument("--cull-zero", action="store_true",
+                    help="do not trace shadow rays whose contribution is exactly zero (same film, fewer rays; off by default: "
+                         "the headline counts the rays the reference's control flow traces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -143,7 +146,8 @@ def main():
     accum = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
 
     # the timed steps carry HIP events around the dominant kernel's launches only (every event pair costs a little)
-    opt = dict(rng_mode=args.rng, traversal=args.traversal, profile_closest=True, streams=args.streams if args.rng == 1 else 0)
+    opt = dict(rng_mode=args.rng, traversal=args.traversal, profile_closest=True, streams=args.streams if args.rng == 1 else 0,
+               cull_zero=args.cull_zero)
     if world > 1 and args.partition == "tile":
         opt.update(tile_rank=rank, tile_world=world)
     elif world > 1:

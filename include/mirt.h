@@ -84,7 +84,10 @@ typedef struct mirt_options {
                                bit 1 = count node visits / triangle tests,
                                bit 2 = progressive pass (mirt_render_accum, rng_mode 1): add this call's samples
                                [sample_begin, sample_begin + sample_count) to what accum_dev already holds instead of
-                               clearing it; mirt_tonemap of the buffer after any pass is the image so far */
+                               clearing it; mirt_tonemap of the buffer after any pass is the image so far,
+                               bit 4 = do not trace shadow rays whose contribution is exactly zero (a light behind the
+                               surface; the reference traces them, raytracer.cuh:38-47, and adds 0): same film, fewer rays
+                               in mirt_stats.shadow_rays (at most 32 shadow rays per hit, else ignored) */
   uint32_t streams;         /* rng_mode 1 only, 0 or 1 = off: S sample streams per pixel in flight at once (stream k renders
                                the k-th contiguous share of the pixel's samples into its own partial sum; the partial sums are
                                added in stream order at the end).  Same samples, S times fewer and S times larger wavefront

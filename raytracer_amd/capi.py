@@ -237,12 +237,14 @@ class Scene:
 
     @staticmethod
     def options(rng_mode=0, seed=0, traversal=0, tile_rank=0, tile_world=1, sample_begin=0, sample_count=0,
-                glass_int_abs=0, profile=False, count=False, streams=0, accumulate=False, profile_closest=False):
+                glass_int_abs=0, profile=False, count=False, streams=0, accumulate=False, profile_closest=False,
+                cull_zero=False):
         o = Options()
         o.rng_mode, o.seed, o.traversal = rng_mode, seed, traversal
         o.tile_rank, o.tile_world = tile_rank, tile_world
         o.sample_begin, o.sample_count, o.glass_int_abs = sample_begin, sample_count, glass_int_abs
-        o.flags = (1 if profile else 0) | (2 if count else 0) | (4 if accumulate else 0) | (8 if profile_closest else 0)
+        o.flags = (1 if profile else 0) | (2 if count else 0) | (4 if accumulate else 0) | (8 if profile_closest else 0) | \
+            (16 if cull_zero else 0)
         o.streams = streams
         return o
 

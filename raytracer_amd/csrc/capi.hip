@@ -704,6 +704,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   a.tri_nrm = s->tri_nrm.as<float4>(); a.mats = s->mats.as<float4>(); a.lights = s->lights.as<float>();
   a.mf_queue = s->mf_queue.as<uint32_t>(); a.mf_count = ctrl + CTRL_MF;
   a.live_16th = G.live_16th;
+  a.cull_zero = ((o.flags & 16u) && K >= 1 && K <= 32) ? 1u : 0u;
 
   const bool profile = stats && (o.flags & 1u);
   const bool profile_closest = stats && (o.flags & 9u);                  // bit 3: time the closest-hit launches only
@@ -835,7 +836,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
           // every later iteration already launched found them empty too)
           n_camera += hc[QC_EXT_FRONT];
           n_bounced += hc[QC_EXT_BACK];
-          n_shadow_rays += hc[QC_SHADOW];
+          n_shadow_rays += hc[QC_SHADOW] - hc[QC_CULLED];
           const uint32_t in_flight = hc[QC_EXT_FRONT] + hc[QC_EXT_BACK] + hc[QC_SHADOW];
           if (in_flight == 0) pp.done = true;
           if (in_flight < pp.a[0].n_slots / 32u) pp.tail = true;

@@ -93,6 +93,7 @@ struct PathCtx {
 struct Emit {
   uint32_t ext;        // 0 none, 1 camera ray (front of the extension queue), 2 bounced ray (back of the same array)
   uint32_t nsh;        // shadow rays written to entries k * n_slots + s, k < nsh (0 or n_lights * spl)
+  uint32_t cull;       // bit k: entry k carries no ray (RenderArgs::cull_zero)
 };
 
 __device__ __forceinline__ void emit_extension(const RenderArgs &a, uint32_t s, const DRay &r, bool primary, Emit &em) {
@@ -297,6 +298,12 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
               float cosv = smax(vdot(is.normal, vunit(sdir)), 0.f);     // raytracer.cuh:45
               V3 contrib = vdiv(vdiv(vscale(vmul(f, Lr), cosv), pdf), (float) a.spl);
               size_t e = (size_t) k * a.n_slots + s;
+              if (a.cull_zero && contrib.x == 0.f && contrib.y == 0.f && contrib.z == 0.f) {
+                // a light behind the surface: whatever the shadow ray finds, the sum does not change (x + 0 = x)
+                a.sh_occ[e] = 1u;
+                em.cull |= 1u << k;
+                continue;
+              }
               a.sh_o[e] = make_float4(so.x, so.y, so.z, MIRT_EPS);
               a.sh_d[e] = make_float4(to_light.x, to_light.y, to_light.z, dist - MIRT_EPS);
               a.sh_c[e] = make_float4(contrib.x, contrib.y, contrib.z, 0);
@@ -379,8 +386,8 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
 #endif
 template<bool MF>
 __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
-  __shared__ uint32_t wave_cnt[4][4];
-  __shared__ uint32_t block_base[4], block_tot[4];
+  __shared__ uint32_t wave_cnt[4][5];
+  __shared__ uint32_t block_base[5], block_tot[5];
   const uint32_t tid = threadIdx.x, wave = tid >> 6;
   const bool listed = !MF && a.live_in != nullptr && (uint64_t) *a.live_in_count * 16u <= (uint64_t) a.n_slots * a.live_16th;
   const uint32_t n = MF ? *a.mf_count : (listed ? *a.live_in_count : a.n_slots);
@@ -389,7 +396,7 @@ __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
     const uint32_t i = base + tid;
     uint32_t s = 0;
     Emit em;
-    em.ext = 0; em.nsh = 0;
+    em.ext = 0; em.nsh = 0; em.cull = 0;
     if (i < n) {
       s = MF ? a.mf_queue[i] : (listed ? a.live_in[i] : i);
       const uint4 st = a.st[s];
@@ -398,14 +405,18 @@ __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
     // (a slot that is not finished has just emitted something; one handed to the MICROFACET kernel is listed by that one)
     const uint64_t m0 = __ballot(em.ext == 1), m1 = __ballot(em.ext == 2), m2 = __ballot(em.nsh != 0),
                    m3 = __ballot(em.ext != 0 || em.nsh != 0);
+    uint32_t n_culled = 0;
+    if (a.cull_zero)
+      for (uint32_t k = 0; k < K; k++) n_culled += (uint32_t) __popcll(__ballot((em.cull >> k) & 1u));
     if ((tid & 63) == 0) {
       wave_cnt[wave][0] = (uint32_t) __popcll(m0);
       wave_cnt[wave][1] = (uint32_t) __popcll(m1);
       wave_cnt[wave][2] = (uint32_t) __popcll(m2);
       wave_cnt[wave][3] = (uint32_t) __popcll(m3);
+      wave_cnt[wave][4] = n_culled;
     }
     __syncthreads();
-    if (tid < 4) {
+    if (tid < 5) {
       const uint32_t tot = wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
       block_tot[tid] = tot;
       block_base[tid] = tot ? atomicAdd(a.qcount + CTR_STRIDE * tid, tid == 2 ? tot * K : tot) : 0u;
@@ -420,7 +431,8 @@ __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
     if (em.nsh) {
       // light-major inside the workgroup's range: consecutive entries go to the same light from neighbouring pixels
       const uint32_t p = block_base[2] + off[2] + lane_rank(m2);
-      for (uint32_t k = 0; k < K; k++) a.sh_queue[p + k * block_tot[2]] = k * a.n_slots + s;
+      for (uint32_t k = 0; k < K; k++)
+        a.sh_queue[p + k * block_tot[2]] = ((em.cull >> k) & 1u) ? QUEUE_SKIP : k * a.n_slots + s;
     }
     if (em.ext != 0 || em.nsh != 0) a.live_out[block_base[3] + off[3] + lane_rank(m3)] = s;
     __syncthreads();
@@ -550,6 +562,7 @@ __global__ void __launch_bounds__(256) k_trace2(TraceArgs a) {
     atomicAdd(a.redo_stat, (unsigned long long) total);
   for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += gridDim.x * blockDim.x) {
     uint32_t id = a.redo ? a.redo_queue[w] : (w < nA ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)]);
+    if (id == QUEUE_SKIP) continue;
     LaneRay r;
     load_ray(a, id, r);
     uint32_t stack[BVH2_STACK];
@@ -729,8 +742,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
       if (!wave_done) {
         if (!active) {
           const uint32_t w = w_next + lane_rank(need);
-          if (w < w_end) {
-            const uint32_t id = (w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)];
+          const uint32_t id = (w < w_end) ? ((w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)]) : QUEUE_SKIP;
+          if (id != QUEUE_SKIP) {                          // (QUEUE_SKIP in the queue: a culled shadow ray)
             load_ray(a, id, r);
             // Slab and hit arithmetic stays finite for these rays; anything else (zero direction components -> 0 * inf,
             // non-finite origins, NaN bounds) makes the reference's result depend on its visiting order: defer to k_trace2.
@@ -1000,8 +1013,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
       if (!wave_done) {
         if (!active) {
           const uint32_t w = w_next + lane_rank(need);
-          if (w < w_end) {
-            const uint32_t id = (w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)];
+          const uint32_t id = (w < w_end) ? ((w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)]) : QUEUE_SKIP;
+          if (id != QUEUE_SKIP) {                          // (QUEUE_SKIP in the queue: a culled shadow ray)
             load_ray(a, id, r);
             // Rays the shortcut arithmetic is not meant for take the reference walk: non-finite origin / direction /
             // reciprocal (the reference's result then depends on its visiting order), a direction almost parallel to an

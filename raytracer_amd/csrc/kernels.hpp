@@ -21,7 +21,9 @@ enum : uint32_t { F_DONE = 1, F_HAS_RAY = 2, F_PENDING = 4, F_AHEAD = 8 };
 // 128-byte line of its own: same-address atomics retire at ~11 ns each on MI355X (tools/micro/atomic_rate.hip) and
 // counters sharing a line queue up behind each other.
 constexpr int CTR_STRIDE = 32;
-enum : int { QC_EXT_FRONT = 0, QC_EXT_BACK = CTR_STRIDE, QC_SHADOW = 2 * CTR_STRIDE, QC_LIVE = 3 * CTR_STRIDE, QC_WORDS = 4 * CTR_STRIDE };
+enum : int { QC_EXT_FRONT = 0, QC_EXT_BACK = CTR_STRIDE, QC_SHADOW = 2 * CTR_STRIDE, QC_LIVE = 3 * CTR_STRIDE,
+             QC_CULLED = 4 * CTR_STRIDE, QC_WORDS = 5 * CTR_STRIDE };
+constexpr uint32_t QUEUE_SKIP = 0xFFFFFFFFu;   // a queue entry no ray stands behind (a culled shadow ray)
 constexpr int WORK_PARTS = 8;        // a trace launch splits its queue into this many ranges, one fetch counter each
 
 struct RenderArgs {
@@ -53,6 +55,7 @@ struct RenderArgs {
   const uint32_t *live_in, *live_in_count;
   uint32_t *live_out;
   uint32_t live_16th;                     // the list is used when it holds at most live_16th / 16 of the slots
+  uint32_t cull_zero;                     // mirt_options.flags bit 4: shadow rays whose contribution is exactly 0 are not traced
   const float *lights;                    // 17 dwords per light (mirt_light)
 };
 

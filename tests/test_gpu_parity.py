@@ -538,3 +538,22 @@ def test_cpp_host_mirror_app_renders_the_same_film(mirt, tmp_path):
     mirt.save_bmp(ref_bmp, img)
     assert open(out, "rb").read() == open(ref_bmp, "rb").read()
     s.close()
+
+
+def test_culling_zero_contribution_shadow_rays_keeps_the_film(mirt):
+    """mirt_options.flags bit 4: a shadow ray whose contribution is exactly zero (light behind the surface) is not traced.
+    x + 0 = x, so the accumulators must be bit-identical; only the shadow-ray count drops."""
+    import torch
+    sc = scenes.conference_scene(20000)
+    w, h = 320, 180
+    out = []
+    for cull in (False, True):
+        s = mirt.Scene(sc)
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+        st = s.render_accum(w, h, acc.data_ptr(), spp=8, depth=6, rng_mode=1, streams=2, cull_zero=cull)
+        out.append((acc.cpu(), st["closest_rays"], st["shadow_rays"]))
+        s.close()
+    assert torch.equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1]
+    assert out[1][2] < out[0][2]
+    print("shadow rays", out[0][2], "->", out[1][2])
