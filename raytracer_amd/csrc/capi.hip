@@ -728,6 +728,12 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   const int n_pipes = (streams >= 2 && !G.serial && !G.one_pipe && part.n_slots) ? 2 : 1;
   // with two pipes four persistent launches share the GPU: 4 workgroups per CU each measured best (tools/sweep_env.sh)
   const uint32_t pipe_blocks = (n_pipes == 2 && !G.blocks_forced) ? 4u : 0u;
+  // (the closest-hit launches are what the frame waits for: the shadow launches get by with one workgroup per CU less)
+  uint32_t shadow_blocks = pipe_blocks ? pipe_blocks - 1 : 0u;
+  if (const char *e = getenv("MIRT_SHADOW_BLOCKS")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 16) shadow_blocks = (uint32_t) v;
+  }
   // Every pipe has two control blocks and two live-slot lists; iteration i counts into block i & 1 and reads the list the
   // iteration before it wrote (so clearing a block never races with a reader of the previous one).
   struct Pipe {
@@ -811,7 +817,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
         if (fork) {
           HIPCHK(hipEventRecord(G.fork_ev[p][slot], main));
           HIPCHK(hipStreamWaitEvent(side, G.fork_ev[p][slot], 0));
-          rc = run_trace(s, pp.ts[par], true, o.traversal, profile ? &timed : nullptr, counting, side, pipe_blocks);
+          rc = run_trace(s, pp.ts[par], true, o.traversal, profile ? &timed : nullptr, counting, side, shadow_blocks);
           if (rc) return rc;
           HIPCHK(hipEventRecord(G.join_ev[p][slot], side));
         }
