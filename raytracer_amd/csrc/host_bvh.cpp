@@ -400,7 +400,8 @@ struct SahBuilder {
   std::vector<uint32_t> &perm;            // = order when the build is done (a leaf's primitives are its range of `order`)
   int fork_depth = 0;
   uint32_t max_leaf;
-  static constexpr int BINS = 16;
+  static constexpr int MAX_BINS = 64;
+  int BINS = 16;                          // MIRT_SAH_BINS
   float peel = 0.5f;                      // primitives whose box area exceeds peel x the node's go into a subtree of their own
                                           // (0 = off; tools/peel_sweep.sh: conference* 135.7 -> 133.3 ms/frame)
 
@@ -511,8 +512,8 @@ struct SahBuilder {
     // binned SAH over the three axes
     int best_axis = -1, best_bin = -1;
     float best_cost = std::numeric_limits<float>::infinity();
-    Box bins[3][BINS];
-    uint32_t cnt[3][BINS];
+    Box bins[3][MAX_BINS];
+    uint32_t cnt[3][MAX_BINS];
     float lo3[3], scale3[3];
     bool use[3];
     for (int ax = 0; ax < 3; ax++) {
@@ -535,8 +536,8 @@ struct SahBuilder {
     }
     for (int ax = 0; ax < 3; ax++) {
       if (!use[ax]) continue;
-      float ra[BINS];
-      uint32_t rn[BINS];
+      float ra[MAX_BINS];
+      uint32_t rn[MAX_BINS];
       Box acc = empty();
       uint32_t c = 0;
       for (int k = BINS - 1; k > 0; k--) { grow(acc, bins[ax][k]); c += cnt[ax][k]; ra[k] = area(acc); rn[k] = c; }
@@ -684,6 +685,10 @@ void build_fast_tree(const float *tri_pos_flat, const uint8_t *prim_type_flat, u
   }
   StageClock clk;
   if (const char *e = std::getenv("MIRT_SAH_PEEL")) sb.peel = (float) std::atof(e);
+  if (const char *e = std::getenv("MIRT_SAH_BINS")) {
+    int v = std::atoi(e);
+    if (v >= 2 && v <= SahBuilder::MAX_BINS) sb.BINS = v;
+  }
   sb.prepare(n);
   clk.lap("own tree: boxes, centroids");
   sb.build(0, n);
