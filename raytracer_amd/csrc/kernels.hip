@@ -135,7 +135,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
   float4 h = make_float4(0, 0, 0, u2f(0xFFFFFFFFu));
   if (has_ray) h = a.hit[s];
   const float4 tot4 = a.total[s];
-  float4 acc4 = a.accum[s];
+  float4 acc4 = make_float4(0, 0, 0, 0);              // loaded when a sample is finished (once in a few iterations)
   float4 m4 = make_float4(0, 0, 0, 0), ro = m4, rd = m4, dm = m4, sc0 = m4, sc1 = m4;
   uint32_t occ0 = 1, occ1 = 1;
   if (has_ray) {
@@ -219,6 +219,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
 
   // finish sample c.i: raytracer.cuh:111-122
   auto finalize = [&]() {
+    if (!acc_dirty) acc4 = a.accum[s];
     acc4.x += total.x; acc4.y += total.y; acc4.z += total.z;
     acc_dirty = true;
     float illum = villum(total);
