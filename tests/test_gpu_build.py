@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from raytracer_amd import scenes
-from test_gpu_parity import SCENES, SPHERE_SCENES, random_rays
+from gpu_common import SCENES, SPHERE_SCENES, random_rays
 from treecheck import check_own_tree
 
 pytestmark = pytest.mark.gpu
