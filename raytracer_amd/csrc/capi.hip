@@ -58,6 +58,7 @@ struct DevBuf {
 };
 
 constexpr int RING = 4;
+constexpr int MAX_PIPES = 4;
 
 struct Global {
   bool ready = false;
@@ -71,9 +72,10 @@ struct Global {
   // with its own pair of streams (main: k_logic + closest-hit traversal, side: shadow traversal), so that the HBM-bound
   // k_logic of one half runs while the other half is in its traversals.  `stream` / `side` are pipe 0's.
   hipStream_t stream = nullptr, side = nullptr;
-  hipStream_t pstream[2] = {}, pside[2] = {};
-  hipEvent_t fork_ev[2][RING] = {}, join_ev[2][RING] = {};
-  hipEvent_t pipe_ev[2] = {};
+  hipStream_t pstream[MAX_PIPES] = {}, pside[MAX_PIPES] = {};
+  hipEvent_t fork_ev[MAX_PIPES][RING] = {}, join_ev[MAX_PIPES][RING] = {};
+  hipEvent_t pipe_ev[MAX_PIPES] = {};
+  int pipes = 2;                        // MIRT_PIPES: independent wavefront loops per frame (1, 2 or 4; needs as many sample streams)
   bool one_pipe = false;
   uint32_t live_16th = 4;               // MIRT_LIVE_16TH: k_logic walks the live-slot list once it is below this share of the slots
   bool blocks_forced = false;           // MIRT_BLOCKS_PER_CU given
@@ -84,7 +86,7 @@ struct Global {
   size_t h_film_words = 0;
   hipEvent_t film_ev[8] = {};
   uint32_t *h_counts = nullptr;          // pinned: 2 pipes x RING x QC_WORDS
-  hipEvent_t ring_ev[2][RING] = {};
+  hipEvent_t ring_ev[MAX_PIPES][RING] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<hipEvent_t> pool;          // timing events for profiled renders (recorded without host syncs)
   size_t pool_used = 0;
@@ -161,7 +163,7 @@ int mirt_init(int device) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
   G.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  for (int p = 0; p < 2; p++) {
+  for (int p = 0; p < MAX_PIPES; p++) {
     HIPCHK(hipStreamCreateWithFlags(&G.pstream[p], hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&G.pside[p], hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&G.pipe_ev[p], hipEventDisableTiming));
@@ -176,7 +178,7 @@ int mirt_init(int device) {
   G.table_exact = build_tonemap_table(G.table);
   HIPCHK(G.d_table.ensure(sizeof(G.table)));
   HIPCHK(hipMemcpy(G.d_table.p, G.table, sizeof(G.table), hipMemcpyHostToDevice));
-  HIPCHK(hipHostMalloc((void **) &G.h_counts, 2 * RING * QC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **) &G.h_counts, MAX_PIPES * RING * QC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
   for (auto &e: G.film_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(hipEventCreate(&G.ev0));
   HIPCHK(hipEventCreate(&G.ev1));
@@ -187,6 +189,10 @@ int mirt_init(int device) {
   }
   if (const char *s = getenv("MIRT_SERIAL")) G.serial = atoi(s) != 0;
   if (const char *s = getenv("MIRT_ONE_PIPE")) G.one_pipe = atoi(s) != 0;
+  if (const char *s = getenv("MIRT_PIPES")) {
+    const int v = atoi(s);
+    if (v == 1 || v == 2 || v == 4) G.pipes = v;
+  }
   if (const char *s = getenv("MIRT_LIVE_16TH")) {
     int v = atoi(s);
     if (v >= 0 && v <= 16) G.live_16th = (uint32_t) v;
@@ -206,7 +212,7 @@ int mirt_init(int device) {
 
 void mirt_shutdown(void) {
   if (!G.ready) return;
-  for (int p = 0; p < 2; p++) {
+  for (int p = 0; p < MAX_PIPES; p++) {
     if (G.pstream[p]) (void) hipStreamSynchronize(G.pstream[p]);
     if (G.pside[p]) (void) hipStreamSynchronize(G.pside[p]);
     if (G.pipe_ev[p]) (void) hipEventDestroy(G.pipe_ev[p]);
@@ -225,7 +231,7 @@ void mirt_shutdown(void) {
   for (auto e: G.pool) (void) hipEventDestroy(e);
   G.d_table.release();
   G.d_rgb.release();
-  for (int p = 0; p < 2; p++) if (G.pstream[p]) (void) hipStreamDestroy(G.pstream[p]);
+  for (int p = 0; p < MAX_PIPES; p++) if (G.pstream[p]) (void) hipStreamDestroy(G.pstream[p]);
   G = Global();
 }
 
@@ -405,8 +411,8 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
     s->trace_threads = (uint32_t) (G.n_cu * G.blocks_per_cu * TRACE_BLOCK);
     int need = std::max(3 * ((int) s->bvh.depth4 + 2), 7 * ((int) s->depth8 + 2)) - LDS_STACK + 1;
     s->ovf_depth = (uint32_t) (need > 1 ? need : 1);
-    // four regions: the closest-hit and the shadow launch of an iteration run concurrently, in each of two pipes
-    ok = s->ovf.ensure(4 * (size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
+    // one region per launch in flight: the closest-hit and the shadow launch of an iteration run concurrently, in each pipe
+    ok = s->ovf.ensure(2 * MAX_PIPES * (size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
   }
   if (!ok) {
     rc = fail(MIRT_E_DEVICE, std::string("scene upload failed: ") + hipGetErrorString(hipGetLastError()));
@@ -549,8 +555,8 @@ int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
   HIPCHK(s->mf_queue.ensure(n * 4));
   HIPCHK(s->live[0].ensure(n * 4));
   HIPCHK(s->live[1].ensure(n * 4));
-  HIPCHK(s->ctrl.ensure(4 * CTRL_WORDS * 4));                          // 2 pipes x 2 (an iteration uses block `iteration & 1`)
-  HIPCHK(s->ray_stats.ensure(2 * 16 * 8));
+  HIPCHK(s->ctrl.ensure(2 * MAX_PIPES * CTRL_WORDS * 4));              // pipes x 2 (an iteration uses block `iteration & 1`)
+  HIPCHK(s->ray_stats.ensure(MAX_PIPES * 16 * 8));
   return MIRT_OK;
 }
 
@@ -719,15 +725,16 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
 
   if (!accumulate) HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
   if (via_planes) HIPCHK(hipMemsetAsync(s->planes.p, 0, (size_t) streams * w * h * 16, G.stream));
-  HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, 2 * 128, G.stream));
-  HIPCHK(hipMemsetAsync(s->ctrl.p, 0, 4 * CTRL_WORDS * 4, G.stream));
+  HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, MAX_PIPES * 128, G.stream));
+  HIPCHK(hipMemsetAsync(s->ctrl.p, 0, 2 * MAX_PIPES * CTRL_WORDS * 4, G.stream));
   HIPCHK(hipEventRecord(evA, G.stream));
 
   // Pipes: with at least two sample streams the slots are split into two halves that run as independent wavefront loops
   // on their own streams (see Global).  One pipe otherwise.
-  const int n_pipes = (streams >= 2 && !G.serial && !G.one_pipe && part.n_slots) ? 2 : 1;
+  int n_pipes = (streams >= 2 && !G.serial && !G.one_pipe && part.n_slots) ? G.pipes : 1;
+  while (n_pipes > 1 && (uint32_t) n_pipes > streams) n_pipes /= 2;
   // with two pipes four persistent launches share the GPU: 4 workgroups per CU each measured best (tools/sweep_env.sh)
-  const uint32_t pipe_blocks = (n_pipes == 2 && !G.blocks_forced) ? 4u : 0u;
+  const uint32_t pipe_blocks = (n_pipes >= 2 && !G.blocks_forced) ? (n_pipes == 2 ? 4u : 3u) : 0u;
   // (the closest-hit launches are what the frame waits for: the shadow launches get by with one workgroup per CU less)
   uint32_t shadow_blocks = pipe_blocks ? pipe_blocks - 1 : 0u;
   if (const char *e = getenv("MIRT_SHADOW_BLOCKS")) {
@@ -742,10 +749,10 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     uint32_t *ctrl[2];
     uint64_t it = 0, accounted = 0;
     bool done = false, tail = false;
-  } pipe[2];
+  } pipe[MAX_PIPES];
   for (int p = 0; p < n_pipes; p++) {
-    const uint32_t s_first = n_pipes == 2 ? (p == 0 ? 0 : streams / 2) : 0;
-    const uint32_t s_count = n_pipes == 2 ? (p == 0 ? streams / 2 : streams - streams / 2) : streams;
+    const uint32_t s_first = streams * (uint32_t) p / (uint32_t) n_pipes;          // a contiguous range of the sample streams
+    const uint32_t s_count = streams * (uint32_t) (p + 1) / (uint32_t) n_pipes - s_first;
     const size_t off = (size_t) s_first * part.n_slots, koff = off * (K ? K : 1);
     Pipe &pp = pipe[p];
     for (int par = 0; par < 2; par++) {
@@ -771,9 +778,9 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   uint32_t iters = 0;
   uint64_t n_camera = 0, n_bounced = 0, n_shadow_rays = 0;
   if (part.n_slots) {
-    if (n_pipes == 2) {                                                  // pipe 1 starts after the clears above
+    if (n_pipes >= 2) {                                                  // the other pipes start after the clears above
       HIPCHK(hipEventRecord(G.pipe_ev[0], G.stream));
-      HIPCHK(hipStreamWaitEvent(G.pstream[1], G.pipe_ev[0], 0));
+      for (int p = 1; p < n_pipes; p++) HIPCHK(hipStreamWaitEvent(G.pstream[p], G.pipe_ev[0], 0));
     }
     for (int p = 0; p < n_pipes; p++) HIPCHK(launch_init(pipe[p].a[0], G.pstream[p]));
     const uint64_t max_iters = (uint64_t) a.spp * ((uint64_t) a.max_depth + 3) + 8;
@@ -849,9 +856,9 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
         }
       }
     }
-    if (n_pipes == 2) {
-      HIPCHK(hipEventRecord(G.pipe_ev[1], G.pstream[1]));
-      HIPCHK(hipStreamWaitEvent(G.stream, G.pipe_ev[1], 0));
+    for (int p = 1; p < n_pipes; p++) {
+      HIPCHK(hipEventRecord(G.pipe_ev[p], G.pstream[p]));
+      HIPCHK(hipStreamWaitEvent(G.stream, G.pipe_ev[p], 0));
     }
   }
   if (via_planes && part.n_slots)
@@ -860,9 +867,9 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   HIPCHK(hipEventSynchronize(evB));
   uint32_t err = 0;
   {
-    std::vector<uint32_t> blocks((size_t) 4 * CTRL_WORDS);               // one copy for the four error flags
+    std::vector<uint32_t> blocks((size_t) 2 * MAX_PIPES * CTRL_WORDS);   // one copy for all the error flags
     HIPCHK(hipMemcpy(blocks.data(), ctrl, blocks.size() * 4, hipMemcpyDeviceToHost));
-    for (int b = 0; b < 4; b++) err |= blocks[(size_t) b * CTRL_WORDS + CTRL_ERR];
+    for (int b = 0; b < 2 * MAX_PIPES; b++) err |= blocks[(size_t) b * CTRL_WORDS + CTRL_ERR];
   }
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, evA, evB));
@@ -876,9 +883,10 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     n_kind[t.kind]++;
   }
   if (stats) {
-    unsigned long long rs[32] = {0};
-    HIPCHK(hipMemcpy(rs, s->ray_stats.p, 256, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 16; k++) rs[k] += rs[16 + k];                    // the two pipes' counters
+    unsigned long long rs[16 * MAX_PIPES] = {0};
+    HIPCHK(hipMemcpy(rs, s->ray_stats.p, sizeof rs, hipMemcpyDeviceToHost));
+    for (int p = 1; p < MAX_PIPES; p++)
+      for (int k = 0; k < 16; k++) rs[k] += rs[16 * p + k];              // the pipes' counters
     memset(stats, 0, sizeof *stats);
     stats->closest_rays = n_camera + n_bounced;
     stats->shadow_rays = n_shadow_rays;
