@@ -191,7 +191,11 @@ int mirt_render(mirt_scene *scene, const mirt_camera *camera, const mirt_params 
 
 /* Same render, but leaves the float accumulation buffer on the device: accum_dev = width*height float4
  * (sum r, sum g, sum b, divisor) in DEVICE memory owned by the caller (e.g. a torch tensor), pixels this process does not
- * own are written as zeros, so a plain sum over processes (RCCL reduce) composes tile and spp partitions. */
+ * own are written as zeros, so a plain sum over processes (RCCL reduce) composes tile and spp partitions.
+ * Stream contract (also mirt_tonemap): the library runs on its own non-blocking HIP streams.  On entry it orders itself
+ * after everything queued so far on the device's NULL stream (torch's default stream), and it returns only when accum_dev is
+ * complete, so NULL-stream users need no synchronisation of their own.  Work the caller has in flight on OTHER streams
+ * that touches accum_dev must be synchronised by the caller before the call. */
 int mirt_render_accum(mirt_scene *scene, const mirt_camera *camera, const mirt_params *params,
                       const mirt_options *opts, uint32_t width, uint32_t height, void *accum_dev, mirt_stats *stats);
 

@@ -87,7 +87,8 @@ struct Global {
   hipEvent_t film_ev[8] = {};
   uint32_t *h_counts = nullptr;          // pinned: 2 pipes x RING x QC_WORDS
   hipEvent_t ring_ev[MAX_PIPES][RING] = {};
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;    // first launch / accumulation buffer complete (render_ms)
+  hipEvent_t ev_in = nullptr;               // entry: recorded on the caller's NULL stream, waited for by `stream`
   std::vector<hipEvent_t> pool;          // timing events for profiled renders (recorded without host syncs)
   size_t pool_used = 0;
   hipEvent_t pool_next() {
@@ -182,6 +183,7 @@ int mirt_init(int device) {
   for (auto &e: G.film_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(hipEventCreate(&G.ev0));
   HIPCHK(hipEventCreate(&G.ev1));
+  HIPCHK(hipEventCreateWithFlags(&G.ev_in, hipEventDisableTiming));
   G.blocks_per_cu = trace4_blocks_per_cu();
   if (const char *s = getenv("MIRT_BLOCKS_PER_CU")) {
     int v = atoi(s);
@@ -225,6 +227,7 @@ void mirt_shutdown(void) {
   }
   if (G.ev0) (void) hipEventDestroy(G.ev0);
   if (G.ev1) (void) hipEventDestroy(G.ev1);
+  if (G.ev_in) (void) hipEventDestroy(G.ev_in);
   if (G.h_counts) (void) hipHostFree(G.h_counts);
   if (G.h_film) (void) hipHostFree(G.h_film);
   for (auto e: G.film_ev) if (e) (void) hipEventDestroy(e);
@@ -248,9 +251,33 @@ int mirt_scene_create_prims(const float *tri_pos, const float *tri_nrm, const ui
                                 out);
 }
 
+static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, const uint8_t *prim_type,
+                             uint32_t n_tris, const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights,
+                             uint32_t n_lights, uint32_t leaf_size, const mirt_build_options *build, mirt_scene **out);
+static thread_local mirt_scene *g_building = nullptr;   // the scene under construction, for the exception path below
+
 int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, const uint8_t *prim_type,
                            uint32_t n_tris, const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights,
                            uint32_t n_lights, uint32_t leaf_size, const mirt_build_options *build, mirt_scene **out) {
+  // no C++ exception crosses the C boundary (std::bad_alloc from the staging vectors, std::system_error from the
+  // builder threads)
+  try {
+    return scene_create_impl(tri_pos, tri_nrm, tri_mat, prim_type, n_tris, mats, n_mats, lights, n_lights, leaf_size, build, out);
+  } catch (const std::exception &ex) {
+    if (g_building) {
+      (void) hipDeviceSynchronize();
+      g_building->release_all();
+      delete g_building;
+      g_building = nullptr;
+    }
+    if (out) *out = nullptr;
+    return fail(MIRT_E_LIMIT, std::string("scene creation failed: ") + ex.what());
+  }
+}
+
+static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat, const uint8_t *prim_type,
+                             uint32_t n_tris, const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights,
+                             uint32_t n_lights, uint32_t leaf_size, const mirt_build_options *build, mirt_scene **out) {
   uint32_t builder = 0;
   if (build) {
     builder = build->own_tree_builder;
@@ -271,6 +298,7 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
     if (prim_type && prim_type[i] != 1 && prim_type[i] != 2) return fail(MIRT_E_ARG, "prim_type must be 1 (SPHERE) or 2 (TRIANGLE)");
   }
   auto *s = new mirt_scene();
+  g_building = s;
   try {
     auto t0 = clk::now();
     build_reference_bvh2(tri_pos, prim_type, n_tris, leaf_size, s->bvh);
@@ -280,10 +308,12 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
     s->build_ms[1] = ms_since(t0);
   } catch (const std::exception &ex) {
     delete s;
+    g_building = nullptr;
     return fail(MIRT_E_LIMIT, ex.what());
   }
   if (s->bvh.depth2 + 2 > (uint32_t) BVH2_STACK) {
     delete s;
+    g_building = nullptr;
     return fail(MIRT_E_LIMIT, "reference BVH deeper than the traversal stack (62 levels)");
   }
   s->n_tris = n_tris;
@@ -316,6 +346,31 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
     memcpy(t + 9, &f, 4);                                             // its own flat index (uniform with the fast tree's copy)
     memcpy(t + 10, &kind, 4);
     t[11] = 0.f;
+    if (!kind) {
+      // Word 11, for the ordered traversal's "too close to call" test (kernels.hip tri_test_near): a lower bound
+      // of the triangle's smallest height (low three mantissa bits cleared: rounded down), and in those bits three flags:
+      // edge v0v1 / v0v2 / v1v2 runs within ~14 degrees of a coordinate axis.  A hit next to a vertex or to such an edge can
+      // lie on an EDGE of one of the reference's node boxes, where the reference's slab test (bbox.cuh:67-79) has
+      // entry ~ exit and decides in the last ulp.
+      const double a[3] = {t[3], t[4], t[5]}, b[3] = {t[6], t[7], t[8]};
+      const double c[3] = {(double) p[6] - p[3], (double) p[7] - p[4], (double) p[8] - p[5]};
+      auto len = [](const double *e) { return std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]); };
+      auto near_axis = [](const double *e) {
+        double m[3] = {std::fabs(e[0]), std::fabs(e[1]), std::fabs(e[2])};
+        std::sort(m, m + 3);
+        return m[1] <= 0.25 * m[2];
+      };
+      const double cr[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+      const double longest = std::max(len(a), std::max(len(b), len(c)));
+      const float hmin = longest > 0 ? (float) (len(cr) / longest * (1.0 - 1e-5)) : 0.f;
+      uint32_t w = 0;
+      if (hmin > 0.f && hmin < INFINITY) {                            // (anything else: 0, every hit inside counts as close)
+        memcpy(&w, &hmin, 4);
+        w &= ~7u;
+      }
+      w |= (near_axis(a) ? 1u : 0u) | (near_axis(b) ? 2u : 0u) | (near_axis(c) ? 4u : 0u);
+      memcpy(t + 11, &w, 4);
+    }
     memcpy(m + 9, &tri_mat[o], 4);
     memcpy(m + 10, &o, 4);
     memcpy(m + 11, &kind, 4);
@@ -391,6 +446,7 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
       rc = fail(MIRT_E_DEVICE, "device tree build failed: " + dt.error);
       s->release_all();
       delete s;
+    g_building = nullptr;
       return rc;
     }
     if (rc_b > 0) {                                        // as for the host builder: traversal 0 runs as 1
@@ -418,15 +474,17 @@ int mirt_scene_create_opts(const float *tri_pos, const float *tri_nrm, const uin
     rc = fail(MIRT_E_DEVICE, std::string("scene upload failed: ") + hipGetErrorString(hipGetLastError()));
     s->release_all();
     delete s;
+    g_building = nullptr;
     return rc;
   }
+  g_building = nullptr;
   *out = s;
   return MIRT_OK;
 }
 
 void mirt_scene_destroy(mirt_scene *s) {
   if (!s) return;
-  if (G.ready) (void) hipStreamSynchronize(G.stream);
+  if (G.ready) (void) hipDeviceSynchronize();                            // every pipe and side stream
   s->release_all();
   delete s;
 }
@@ -719,9 +777,16 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   uint32_t n_kind[3] = {0, 0, 0};
   std::vector<Timed> timed;
   G.pool_used = 0;
-  hipEvent_t evA, evB;
-  HIPCHK(hipEventCreate(&evA));
-  HIPCHK(hipEventCreate(&evB));
+  const hipEvent_t evA = G.ev0, evB = G.ev1;
+  // Whatever fails below, nothing of this call is left running on any of the library's streams when it returns.
+  struct Drain {
+    bool armed = true;
+    ~Drain() { if (armed) (void) hipDeviceSynchronize(); }
+  } drain;
+  // accum_dev belongs to the caller, who may have queued work on it: everything here is ordered after what the device's
+  // NULL stream holds at this point (torch's default stream); see mirt.h for the contract.
+  HIPCHK(hipEventRecord(G.ev_in, nullptr));
+  HIPCHK(hipStreamWaitEvent(G.stream, G.ev_in, 0));
 
   if (!accumulate) HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
   if (via_planes) HIPCHK(hipMemsetAsync(s->planes.p, 0, (size_t) streams * w * h * 16, G.stream));
@@ -795,7 +860,6 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
         uint32_t *hcounts = G.h_counts + (size_t) p * RING * QC_WORDS;
         const uint64_t it = pp.it++;
         if (it >= max_iters + RING) {
-          (void) hipDeviceSynchronize();
           return fail(MIRT_E_DEVICE, "wavefront loop did not terminate");
         }
         const int par = (int) (it & 1);
@@ -873,8 +937,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   }
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, evA, evB));
-  (void) hipEventDestroy(evA);
-  (void) hipEventDestroy(evB);
+  drain.armed = false;                                                   // evB has completed: every stream has joined G.stream
   if (err) return fail(MIRT_E_LIMIT, "traversal stack overflow on the device (BVH too deep)");
   for (const Timed &t: timed) {
     float tms = 0;
@@ -937,6 +1000,8 @@ int mirt_tonemap(const void *accum_dev, uint32_t width, uint32_t height, int32_t
   }
   // one packed word per pixel crosses PCIe, in a few pieces; host threads widen each piece to three ints as it lands
   constexpr int PIECES = 8;
+  HIPCHK(hipEventRecord(G.ev_in, nullptr));                              // after the caller's NULL-stream work on accum_dev
+  HIPCHK(hipStreamWaitEvent(G.stream, G.ev_in, 0));
   hipError_t e = launch_tonemap(accum_dev, (uint32_t) n, G.d_table.as<float>(), G.d_rgb.as<uint32_t>(), G.stream);
   size_t cut[PIECES + 1];
   for (int k = 0; k <= PIECES; k++) cut[k] = n * (size_t) k / PIECES;

@@ -536,8 +536,19 @@ __device__ __forceinline__ bool tri_test_near(const float4 *tris, uint32_t idx, 
   const float bx = 1 - by - bz;
   const bool inside = !(t < 0 || bx < 0 || by < 0 || bz < 0);
   const float band = near_rel * fabsf(t);                 // t finite here or the comparisons below are false / handled by the caller
-  near = inside && (fabsf(t - max_t) <= band || fabsf(t - r.min_t) <= band);
-  return inside && !(t <= r.min_t || t > max_t);
+  // Second reason to hand a ray over: the hit lies within EDGE_EPS * t of a vertex, or of an edge that runs close to a
+  // coordinate axis.  Only there can the hit point sit on an EDGE of a reference node box (the box contains the triangle,
+  // so its edges touch it in vertices or along such edges), where the reference's slab test has entry ~ exit and can lose
+  // the hit to rounding - whatever the neighbouring triangles do.  b_i * hmin <= distance to the edge opposite vertex i.
+  constexpr float EDGE_EPS = 4.0e-6f;
+  const uint32_t w11 = f2u(q2.w);
+  const float hmin = u2f(w11 & ~7u), eband = EDGE_EPS * fabsf(t);
+  const float bmax = fmaxf(bx, fmaxf(by, bz));
+  const bool at_rim = ((1.0f - bmax) * hmin <= eband) || ((w11 & 1u) && bz * hmin <= eband) ||
+                      ((w11 & 2u) && by * hmin <= eband) || ((w11 & 4u) && bx * hmin <= eband);
+  const bool accept = inside && !(t <= r.min_t || t > max_t);
+  near = (inside && (fabsf(t - max_t) <= band || fabsf(t - r.min_t) <= band)) || (accept && at_rim);
+  return accept;
 }
 
 // -------------------------------------------------------------------------------------------- k_trace2 (reference walk)

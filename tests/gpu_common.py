@@ -30,3 +30,34 @@ def random_rays(sc, n, seed, unit):
     r[n // 8: n // 4, 3] = 0.0                                       # zero direction component: 0 * inf slabs
     r[n // 4: n // 4 + 60, 3:6] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 60)] * rng.choice([-1, 1], (60, 1))
     return r
+
+
+def aimed_rays(sc, n, seed):
+    """Rays aimed exactly at triangle vertices and edge midpoints (targets and directions computed in float32), from
+    axis-aligned and generic origins, unit directions.  A hit on a vertex or on an axis-parallel edge can sit on an EDGE of
+    one of the reference's node boxes, where its slab test (bbox.cuh:67-79) has entry ~ exit and decides in the last ulp."""
+    rng = np.random.default_rng(seed)
+    f = np.float32
+    tri = sc.pos.reshape(-1, 3, 3)
+    if sc.ptype is not None:
+        tri = tri[sc.ptype == 2]
+    pick = rng.integers(0, len(tri), n)
+    which = rng.integers(0, 6, n)                      # 0..2 vertex, 3..5 midpoint of the edge starting there
+    a = tri[pick, which % 3]
+    b = tri[pick, (which + 1) % 3]
+    tgt = np.where((which >= 3)[:, None], (a + b) * f(0.5), a).astype(np.float32)
+    kind = rng.integers(0, 3, n)                       # 0 axis-aligned origin, 1 generic origin, 2 generic, far away
+    axis = np.eye(3, dtype=np.float32)[rng.integers(0, 3, n)] * rng.choice([-1, 1], (n, 1)).astype(np.float32)
+    gen = rng.normal(size=(n, 3)).astype(np.float32)
+    gen /= np.linalg.norm(gen, axis=1, keepdims=True).astype(np.float32)
+    dist = np.where(kind == 2, rng.uniform(5, 40, n), rng.uniform(0.3, 3, n)).astype(np.float32)[:, None]
+    org = (tgt - np.where((kind == 0)[:, None], axis, gen) * dist).astype(np.float32)
+    d = (tgt - org).astype(np.float32)
+    ln = np.sqrt((d * d).sum(1, dtype=np.float32), dtype=np.float32)[:, None]
+    d = (d / ln).astype(np.float32)
+    r = np.zeros((n, 8), np.float32)
+    r[:, :3] = org
+    r[:, 3:6] = d
+    r[:, 6] = 1e-5
+    r[:, 7] = np.inf
+    return r

@@ -1,0 +1,285 @@
+"""Every BASELINE configuration under `-m gpu`: the HIP path (C ABI) against films and hits the REFERENCE ITSELF produced
+(tests/golden/configs.npz, dumped from oracle/_ref by oracle/make_golden_configs.py), against the C oracle on the box, and --
+at the configurations' own sizes, where the oracle would take minutes -- through properties that do not need it.
+
+Bars as in test_gpu_parity.py: hit indices / t bits / ray counts bit-exact; films in reference-RNG mode >= 99.9 % of the
+bytes identical (device libm rounds sinf/cosf/acosf differently in the last ulp); counter-RNG radiance: rRMSE <= 1.5 x the
+reference-vs-reference rRMSE at equal spp and mean luminance within 1 %.
+"""
+import numpy as np
+import pytest
+
+from gpu_common import aimed_rays, random_rays
+from raytracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _film_check(s, g, key, travs=(0, 1), fabs_key="_rgb_fabs", **opt):
+    w, h, spp, spl, batch, depth = (int(v) for v in g[key + "_params"])
+    tol = float(g[key + "_tol"])
+    want = g[key + fabs_key].astype(np.int32)
+    for trav in travs:
+        img = s.render(w, h, spp=spp, spl=spl, batch=batch, tol=tol, depth=depth, traversal=trav, **opt)
+        same = (img == want).mean()
+        assert same >= 0.999, f"{key}, traversal {trav}: only {same:.5f} of the film bytes equal the reference's"
+        assert abs(img.mean() - want.mean()) < 0.05
+        assert s.last["traversal_used"] == trav
+
+
+def _hits_check(s, g, key):
+    w, h = int(g[key + "_params"][0]), int(g[key + "_params"][1])
+    for trav in (0, 1, 2):
+        idx, tb = s.primary_hits(w, h, traversal=trav)
+        assert (idx == g[key + "_hit_idx"]).all(), f"{key}, traversal {trav}: {(idx != g[key + '_hit_idx']).sum()} hit indices differ"
+        assert (tb == g[key + "_hit_tbits"]).all(), f"{key}, traversal {trav}: t bits differ"
+
+
+def test_cfg1_bunny_256_full_size_vs_the_reference(mirt, golden):
+    """BASELINE configs[0] at its own size (bunny*, 256x256, 4 spp, depth 4, diffuse): the film and the 65 536 primary hits
+    the reference's CPU path produced."""
+    g = golden("configs")
+    sc = scenes.blob_scene(264, 132)
+    sc.camera = sc.camera.for_aspect(256, 256)
+    s = mirt.Scene(sc)
+    _hits_check(s, g, "cfg1")
+    _film_check(s, g, "cfg1")
+    assert s.last["paths"] == 256 * 256 * 4
+    s.close()
+
+
+def test_cfg5_sportscar_materials_vs_the_reference(mirt, golden, oracle):
+    """The material set of BASELINE configs[4] (all 37 materials of objects/sportsCar.mtl: glass ior 1.0, mirror, microfacet,
+    5 emitters) on a 4 562-triangle cut of the stand-in: hits and film from the reference, both abs() variants."""
+    g = golden("configs")
+    sc = scenes.sportscar_scene(6000)
+    sc.camera = sc.camera.for_aspect(96, 54)
+    types = set(int(t) for t in sc.mats[:, 0])
+    assert {scenes.GLASS, scenes.MICROFACET, scenes.REFLECTION, scenes.EMISSION, scenes.DIFFUSE} <= types
+    s = mirt.Scene(sc)
+    _hits_check(s, g, "sportscar")
+    _film_check(s, g, "sportscar")
+    _film_check(s, g, "sportscar", travs=(0,), fabs_key="_rgb", glass_int_abs=1)
+    # same control flow => same ray counts as the oracle (whose films equal the reference's bit for bit on the CPU)
+    oracle.set_glass_float_abs(1)
+    oracle.load(sc)
+    oracle.render(96, 54, spp=4, depth=8, batch=5, tol=0.0)
+    s.render(96, 54, spp=4, depth=8, batch=5, tol=0.0)
+    ours, theirs = (s.last["closest_rays"], s.last["shadow_rays"]), (oracle.last["closest"], oracle.last["shadow"])
+    oracle.set_glass_float_abs(0)
+    assert abs(ours[0] - theirs[0]) <= 0.001 * theirs[0] and abs(ours[1] - theirs[1]) <= 0.001 * theirs[1], (ours, theirs)
+    s.close()
+
+
+def test_cfg5_sportscar_full_size_properties(mirt):
+    """BASELINE configs[4] at its own size: sportsCar* (287 586 triangles, 37 materials) at 3840x2160.  Three traversals
+    agree on 8.3 M primary hits (mode 2 IS the reference's walk); the frame is deterministic; spp slices, sample streams and
+    progressive passes trace exactly the same rays and agree to float re-association; the microfacet kernel runs."""
+    torch = pytest.importorskip("torch")
+    sc = scenes.sportscar_scene()
+    w, h, spp = 3840, 2160, 4
+    sc.camera = sc.camera.for_aspect(w, h)
+    assert (sc.mats[:, 0] == scenes.MICROFACET).any()
+    s = mirt.Scene(sc)
+    i2, t2 = s.primary_hits(w, h, traversal=2)
+    for trav in (0, 1):
+        i, t = s.primary_hits(w, h, traversal=trav)
+        assert (i == i2).all() and (t == t2).all(), f"traversal {trav}: {(i != i2).sum()} of {w * h} primary hits differ"
+    mf_prims = np.isin(sc.mat, np.nonzero(sc.mats[:, 0] == scenes.MICROFACET)[0])
+    _, flat = s.bvh2()
+    assert mf_prims[flat[i2[i2 >= 0]]].sum() > 1000                 # primary rays do land on the microfacet material
+    kw = dict(spp=spp, spl=1, batch=spp + 1, tol=0.0, depth=8, rng_mode=1)
+    full = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    st = dict(s.render_accum(w, h, full.data_ptr(), **kw))
+    rays = (st["closest_rays"], st["shadow_rays"], st["paths"])
+    assert st["paths"] == w * h * spp and st["traversal_used"] == 0
+    again = torch.zeros_like(full)
+    s.render_accum(w, h, again.data_ptr(), **kw)
+    assert torch.equal(full, again)
+    acc = torch.zeros_like(full)
+    stv = s.render_accum(w, h, acc.data_ptr(), streams=4, **kw)
+    assert (stv["closest_rays"], stv["shadow_rays"], stv["paths"]) == rays
+    assert torch.allclose(acc, full, rtol=2e-5, atol=1e-6)
+    prog = torch.zeros_like(full)
+    n = [0, 0, 0]
+    for p in range(2):                                             # "progressive, spp-sliced": two passes of 2 spp
+        stp = s.render_accum(w, h, prog.data_ptr(), sample_begin=2 * p, sample_count=2, accumulate=p > 0, streams=2, **kw)
+        n = [a + b for a, b in zip(n, (stp["closest_rays"], stp["shadow_rays"], stp["paths"]))]
+    assert tuple(n) == rays and torch.allclose(prog, full, rtol=2e-5, atol=1e-6)
+    film = mirt.tonemap(full.data_ptr(), w, h)
+    assert (mirt.tonemap(prog.data_ptr(), w, h) == film).mean() >= 0.999
+    assert 5 < film.mean() < 250
+    s.close()
+
+
+@pytest.mark.parametrize("name,nu,nv,w,h", [("bunny*", 264, 132, 160, 90), ("buddha*", 1024, 512, 128, 72)])
+def test_shaded_frames_of_bunny_and_buddha_vs_oracle(mirt, oracle, name, nu, nv, w, h):
+    """configs[1] / configs[2] geometry, shaded (k_logic, shadow rays, film), depth 8: reference-RNG films against the C oracle
+    on the box, then the 1080p frame in counter mode through properties."""
+    torch = pytest.importorskip("torch")
+    sc = scenes.blob_scene(nu, nv, name)
+    sc.camera = sc.camera.for_aspect(w, h)
+    oracle.load(sc)
+    ref = oracle.render(w, h, spp=4, depth=8, batch=5, tol=0.0, nthreads=8)
+    s = mirt.Scene(sc)
+    for trav in (0, 1):
+        img = s.render(w, h, spp=4, depth=8, batch=5, tol=0.0, traversal=trav)
+        assert (img == ref).mean() >= 0.999, f"traversal {trav}: {(img == ref).mean():.5f}"
+        _counts_close(s, oracle)
+    oracle.set_rng(1, 11)
+    ref = oracle.render(w, h, spp=4, depth=8, batch=5, tol=0.0, nthreads=8)
+    img = s.render(w, h, spp=4, depth=8, batch=5, tol=0.0, rng_mode=1, seed=11)
+    oracle.set_rng(0, 0)
+    assert (img == ref).mean() >= 0.999
+    _counts_close(s, oracle)
+    s.set_camera(sc.camera.for_aspect(1920, 1080))
+    W, H, spp = 1920, 1080, 8
+    kw = dict(spp=spp, spl=1, batch=spp + 1, tol=0.0, depth=8, rng_mode=1)
+    full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    st = dict(s.render_accum(W, H, full.data_ptr(), **kw))
+    assert st["paths"] == W * H * spp and (full[..., 3] == spp).all()
+    acc = torch.zeros_like(full)
+    stv = s.render_accum(W, H, acc.data_ptr(), streams=4, **kw)
+    assert (stv["closest_rays"], stv["shadow_rays"]) == (st["closest_rays"], st["shadow_rays"])
+    assert torch.allclose(acc, full, rtol=2e-5, atol=1e-6)
+    part = torch.zeros_like(full)
+    total = torch.zeros_like(full)
+    for r in range(2):
+        s.render_accum(W, H, part.data_ptr(), sample_begin=4 * r, sample_count=4, **kw)
+        total += part
+    assert torch.allclose(total, full, rtol=2e-5, atol=1e-6)
+    s.close()
+
+
+def _counts_close(s, oracle, rel=1e-3):
+    """Same RNG stream => same control flow, up to the few paths whose bounce direction moved by an ulp of the device libm
+    across a silhouette (closed rooms: exactly equal, test_gpu_parity.py)."""
+    ours, theirs = (s.last["closest_rays"], s.last["shadow_rays"]), (oracle.last["closest"], oracle.last["shadow"])
+    assert abs(ours[0] - theirs[0]) <= rel * theirs[0] and abs(ours[1] - theirs[1]) <= rel * theirs[1], (ours, theirs)
+
+
+def _rrmse(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)) / np.mean(b))
+
+
+def test_radiance_rrmse_all_six_bsdfs_vs_reference(mirt, golden):
+    """Counter-RNG radiance through GLASS / MICROFACET / REFRACTION / REFLECTION / EMISSION / DIFFUSE against two independent
+    256-spp runs of the reference.  Per-pixel means are clamped at 2.0 (4.4 x the mean radiance) before the rRMSE: the
+    scene has caustic paths whose single fireflies (the reference's own run `a` holds one of 4.06) otherwise decide the
+    metric; three seeds."""
+    torch = pytest.importorskip("torch")
+    g = golden("configs")
+    w, h, spp, depth = (int(v) for v in g["mixed_params"])
+    c = lambda x: np.minimum(x, 2.0)
+    a, b = g["mixed_a"], g["mixed_b"]
+    base = _rrmse(c(a), c(b))
+    lum = lambda x: float((x @ np.array([0.2126, 0.7152, 0.0722])).mean())
+    s = mirt.Scene(scenes.cornell_scene(2, "mixed"))
+    for seed in (3, 4, 5):
+        acc = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+        s.render_accum(w, h, acc.data_ptr(), spp=spp, batch=spp + 1, depth=depth, rng_mode=1, seed=seed, streams=4)
+        acc = acc.cpu().numpy()
+        assert (acc[..., 3] == spp).all()
+        rad = acc[..., :3] / acc[..., 3:4]
+        assert _rrmse(c(rad), c(a)) <= 1.5 * base and _rrmse(c(rad), c(b)) <= 1.5 * base, (seed, _rrmse(c(rad), c(a)), base)
+        assert abs(lum(c(rad)) / lum(0.5 * (c(a) + c(b))) - 1) <= 0.01
+    s.close()
+
+
+def test_thin_lens_camera_vs_the_reference(mirt, golden, oracle):
+    """Camera::generate_ray_for_thin_lens (scene/camera.cuh:46-60), aperture 0.05, on the all-BSDF scene: film from the
+    reference, ray counts from the oracle."""
+    g = golden("configs")
+    sc = scenes.cornell_scene(2, "mixed")
+    sc.camera = scenes.Camera((0, 1.5, -1.95), (0, 1.2, 0), hfov=70, vfov=55, aperture=0.05, focal=0.0)
+    s = mirt.Scene(sc)
+    _film_check(s, g, "thinlens")
+    _film_check(s, g, "thinlens", travs=(0,), fabs_key="_rgb", glass_int_abs=1)
+    pin = mirt.Scene(scenes.cornell_scene(2, "mixed"))
+    sharp = pin.render(64, 48, spp=4, depth=5, batch=5, tol=0.0)
+    pin.close()
+    assert (sharp != g["thinlens_rgb_fabs"]).mean() > 0.3          # the lens does something
+    oracle.set_glass_float_abs(1)
+    oracle.load(sc)
+    oracle.render(64, 48, spp=4, depth=5, batch=5, tol=0.0)
+    oracle.set_glass_float_abs(0)
+    s.render(64, 48, spp=4, depth=5, batch=5, tol=0.0)
+    ours, theirs = s.last["closest_rays"] + s.last["shadow_rays"], oracle.last["closest"] + oracle.last["shadow"]
+    assert abs(ours - theirs) <= 0.002 * theirs, (ours, theirs)
+    s.close()
+
+
+def _open_meshes():
+    blob = scenes.blob_scene(64, 32)
+    cen = blob.pos.reshape(-1, 3, 3).mean(1)
+    keep = (cen[:, 1] > 1.1) & (np.arange(blob.n) < blob.n - 2)     # the upper half of the blob: an open rim, no floor
+    cut = scenes.SceneData("cut", blob.pos[keep], blob.nrm[keep], blob.mat[keep], blob.mats, blob.lights, blob.camera).finalize()
+    keep = np.arange(blob.n) >= blob.n - 2
+    quad = scenes.SceneData("quad", np.concatenate([blob.pos[keep], blob.pos[keep] + np.float32(0.37)]),
+                            np.concatenate([blob.nrm[keep]] * 2), np.zeros(4, np.uint32), blob.mats, blob.lights,
+                            blob.camera).finalize()
+    return {"quad": quad, "soup": scenes.random_soup(500, 1), "cut": cut, "cornell": scenes.cornell_scene(1, "diffuse"),
+            "conf": scenes.conference_scene(20000)}
+
+
+@pytest.mark.parametrize("key", ["quad", "soup", "cut", "cornell", "conf"])
+def test_rays_aimed_at_vertices_and_edges(mirt, oracle, key):
+    """The soundness condition of traversal 0 that random rays never meet: a hit ON a vertex or on an
+    axis-parallel edge can lie on an edge of a reference node box, where the reference's slab test decides in the last ulp
+    and LOSES hits (a brute-force walk over all primitives disagrees with the reference on 1-4 % of these rays).  120 000
+    rays aimed at vertices and edge midpoints, open and closed meshes, closest hit and occlusion, against the oracle."""
+    sc = _open_meshes()[key]
+    oracle.load(sc)
+    s = mirt.Scene(sc)
+    rays = aimed_rays(sc, 120000, 17)
+    ci, ct = oracle.trace(rays)
+    ai, _ = oracle.trace(rays, anyhit=True)
+    for trav in (0, 1):
+        gi, gt = s.trace(rays, traversal=trav)
+        assert (gi == ci).all() and (gt == ct).all(), f"{key}: closest, traversal {trav}: {(gi != ci).sum()} of {len(rays)} differ"
+        hi, _ = s.trace(rays, anyhit=True, traversal=trav)
+        assert (hi == ai).all(), f"{key}: any-hit, traversal {trav}: {(hi != ai).sum()} differ"
+    assert (ci >= 0).mean() > 0.4
+    s.close()
+
+
+def test_one_hundred_thousand_spheres(mirt, oracle):
+    """SURVEY 8(f) rank 4 at the scale the reference's app uses spheres (apps/app.cu: 5e5 emissive particles): 120 000
+    spheres over a floor.  Three traversals agree on 230 k primary hits; closest-hit and occlusion queries of 10 000 arbitrary
+    rays equal the oracle's."""
+    rng = np.random.default_rng(5)
+    n = 120000
+    pos = np.zeros((n + 2, 9), np.float32)
+    pos[:n, 0] = rng.normal(0, 1.2, n)
+    pos[:n, 1] = rng.uniform(0.05, 3.0, n)
+    pos[:n, 2] = rng.normal(0, 1.2, n)
+    pos[:n, 3] = rng.uniform(0.004, 0.03, n)
+    pos[n] = [-8, 0, -8, 8, 0, -8, 8, 0, 8]
+    pos[n + 1] = [-8, 0, -8, -8, 0, 8, 8, 0, 8]
+    nrm = np.zeros((n + 2, 9), np.float32)
+    nrm[n:] = [0, 1, 0] * 3
+    mat = np.concatenate([rng.integers(1, 4, n), [0, 0]]).astype(np.uint32)
+    mats = np.array([scenes.WHITE, scenes.emission(2, 1, .5), scenes.emission(1, 2, .5), scenes.RED])
+    sc = scenes.SceneData("particles", pos, nrm, mat, mats, np.array([scenes.point_light((3, 3, 3), (0, 5, 0))]),
+                          scenes.Camera((0, 2.5, -7), (0, 1.2, 0), hfov=42, vfov=42 * 360 / 640),
+                          ptype=np.concatenate([np.full(n, 1, np.uint8), np.full(2, 2, np.uint8)])).finalize()
+    s = mirt.Scene(sc)
+    i2, t2 = s.primary_hits(640, 360, traversal=2)
+    for trav in (0, 1):
+        i, t = s.primary_hits(640, 360, traversal=trav)
+        assert (i == i2).all() and (t == t2).all(), f"traversal {trav}: {(i != i2).sum()} differ"
+    assert len(np.unique(i2)) > 5000
+    oracle.load(sc)
+    rays = random_rays(sc, 10000, 23, True)
+    rays[:, :3] = np.clip(rays[:, :3], -3, 3)
+    ci, ct = oracle.trace(rays)
+    ai, _ = oracle.trace(rays, anyhit=True)
+    for trav in (0, 1, 2):
+        gi, gt = s.trace(rays, traversal=trav)
+        assert (gi == ci).all() and (gt == ct).all(), f"closest, traversal {trav}: {(gi != ci).sum()} differ"
+        hi, _ = s.trace(rays, anyhit=True, traversal=trav)
+        assert (hi == ai).all(), f"any-hit, traversal {trav}"
+    img = s.render(320, 180, spp=2, depth=4, batch=3, tol=0.0)
+    ref = oracle.render(320, 180, spp=2, depth=4, batch=3, tol=0.0, nthreads=8)
+    assert (img == ref).mean() >= 0.999
+    s.close()
