@@ -320,7 +320,7 @@ static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const u
   s->n_mats = n_mats;
   s->n_lights = n_lights;
 
-  // triangles in the reference's flat order: (p1, e1, e2) for the intersector, (n1, n2, n3, material, original id) for shading
+  // triangles in the reference's flat order: (p1, p2, p3) for the intersector, (n1, n2, n3, material, original id) for shading
   std::vector<float> tri((size_t) n_tris * 12), nrm((size_t) n_tris * 12);
   std::atomic<bool> sphere_seen{false};
   parallel_for(n_tris, [&](size_t f0, size_t f1) {
@@ -338,39 +338,14 @@ static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const u
       memset(m, 0, 9 * sizeof(float));
       m[0] = p[0]; m[1] = p[1]; m[2] = p[2];
     } else {
-      t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
-      t[3] = p[3] - p[0]; t[4] = p[4] - p[1]; t[5] = p[5] - p[2];     // e1 = p2 - p1 (primitives.cuh:138)
-      t[6] = p[6] - p[0]; t[7] = p[7] - p[1]; t[8] = p[8] - p[2];     // e2 = p3 - p1 (primitives.cuh:139)
+      // p1 p2 p3 as given: the intersector forms e1 = p2 - p1, e2 = p3 - p1 itself (primitives.cuh:138-139), and the ordered
+      // traversal needs the exact vertices for the primitive's own bounding box (kernels.hip tri_test_near)
+      memcpy(t, p, 9 * sizeof(float));
       memcpy(m, q, 9 * sizeof(float));
     }
     memcpy(t + 9, &f, 4);                                             // its own flat index (uniform with the fast tree's copy)
     memcpy(t + 10, &kind, 4);
     t[11] = 0.f;
-    if (!kind) {
-      // Word 11, for the ordered traversal's "too close to call" test (kernels.hip tri_test_near): a lower bound
-      // of the triangle's smallest height (low three mantissa bits cleared: rounded down), and in those bits three flags:
-      // edge v0v1 / v0v2 / v1v2 runs within ~14 degrees of a coordinate axis.  A hit next to a vertex or to such an edge can
-      // lie on an EDGE of one of the reference's node boxes, where the reference's slab test (bbox.cuh:67-79) has
-      // entry ~ exit and decides in the last ulp.
-      const double a[3] = {t[3], t[4], t[5]}, b[3] = {t[6], t[7], t[8]};
-      const double c[3] = {(double) p[6] - p[3], (double) p[7] - p[4], (double) p[8] - p[5]};
-      auto len = [](const double *e) { return std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]); };
-      auto near_axis = [](const double *e) {
-        double m[3] = {std::fabs(e[0]), std::fabs(e[1]), std::fabs(e[2])};
-        std::sort(m, m + 3);
-        return m[1] <= 0.25 * m[2];
-      };
-      const double cr[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-      const double longest = std::max(len(a), std::max(len(b), len(c)));
-      const float hmin = longest > 0 ? (float) (len(cr) / longest * (1.0 - 1e-5)) : 0.f;
-      uint32_t w = 0;
-      if (hmin > 0.f && hmin < INFINITY) {                            // (anything else: 0, every hit inside counts as close)
-        memcpy(&w, &hmin, 4);
-        w &= ~7u;
-      }
-      w |= (near_axis(a) ? 1u : 0u) | (near_axis(b) ? 2u : 0u) | (near_axis(c) ? 4u : 0u);
-      memcpy(t + 11, &w, 4);
-    }
     memcpy(m + 9, &tri_mat[o], 4);
     memcpy(m + 10, &o, 4);
     memcpy(m + 11, &kind, 4);

@@ -485,7 +485,7 @@ __device__ __forceinline__ SphereHit sphere_eval(const float4 q0, const float4 q
   return h;
 }
 
-// Moeller-Trumbore exactly as primitives.cuh:137-158 evaluates it (e1, e2 are stored: same subtraction, same bits).
+// Moeller-Trumbore exactly as primitives.cuh:137-158 evaluates it (the record holds p1 p2 p3).
 // Returns the reference's accept decision against `max_t`.  Word 10 of the record: 0 triangle, 1 sphere.
 __device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const LaneRay &r, float max_t, float &t,
                                          float &by, float &bz, uint32_t &flat) {
@@ -496,7 +496,8 @@ __device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const
     t = h.t; by = 0.f; bz = 0.f;
     return h.cand && !(h.t > max_t);
   }
-  const V3 p1 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
+  const V3 p1 = mk(q0.x, q0.y, q0.z), p2 = mk(q0.w, q1.x, q1.y), p3 = mk(q1.z, q1.w, q2.x);
+  const V3 e1 = vsub(p2, p1), e2 = vsub(p3, p1);          // primitives.cuh:138-139
   const V3 s = vsub(r.o, p1);
   const V3 s1 = vcross(r.d, e2);
   const V3 s2 = vcross(s, e1);
@@ -508,10 +509,30 @@ __device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const
   return !(t < 0 || t <= r.min_t || t > max_t || bx < 0 || by < 0 || bz < 0);
 }
 
-// The ordered traversal's variant: same arithmetic and accept decision, plus `near`: the primitive is hit (a triangle
-// inside its edges, a sphere at either root) at a distance within NEAR (relative) of one of the two limits the accept test
-// compares against.  For such a hit the reference's own outcome hangs on whether ITS leaf box passed `tmin <= tmax`
-// (bbox.cuh:77) in the last ulps, which no other tree can know: the caller hands the ray to the reference walk (k_redo).
+// The reference's slab test (bbox.cuh:67-79) of the ray against the primitive's OWN bounding box [lo, hi], with the hit
+// distance standing in for max_t.  Every box of the reference's tree above the primitive contains this box, and the slab
+// arithmetic is monotone in the box bounds (lo' <= lo gives (lo' - o) * inv on the same side of (lo - o) * inv, rounding
+// included), so when this test passes every one of them passes too - whatever the reference's tree looks like - and the
+// reference reaches the primitive and takes the same decision on it.  (Finite operands only: the caller has set aside
+// rays with zero / non-finite components, for which the min/max chains below equal the reference's std::max/std::min.)
+__device__ __forceinline__ bool own_box_admits(const V3 lo, const V3 hi, const LaneRay &r, float t_hit) {
+  const float ax = (lo.x - r.o.x) * r.inv.x, bx = (hi.x - r.o.x) * r.inv.x;
+  const float ay = (lo.y - r.o.y) * r.inv.y, by = (hi.y - r.o.y) * r.inv.y;
+  const float az = (lo.z - r.o.z) * r.inv.z, bz = (hi.z - r.o.z) * r.inv.z;
+  const float tmn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+  const float tmx = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_hit));
+  return tmn <= tmx && tmx > r.min_t;
+}
+
+// The ordered traversal's variant: same arithmetic and accept decision, plus `near` = "the reference's outcome for this
+// ray may hang on the reference's own boxes or visiting order, which no other tree can know": the caller hands the ray to
+// the reference walk (k_redo).  Two reasons:
+//   * the primitive is hit (a triangle inside its edges, a sphere at either root) at a distance within NEAR (relative) of
+//     one of the two limits the accept test compares against: a tie, decided by the order of the reference's walk;
+//   * the hit is accepted but the ray fails the reference's slab test on the primitive's own bounding box (own_box_admits):
+//     a hit on a vertex or edge that sits on an edge of that box (entry ~ exit, decided in the last ulp), or a grazing
+//     "hit" that Moeller-Trumbore reports from outside the triangle (its barycentrics are ill-conditioned when the ray runs
+//     almost in the triangle's plane).  The reference finds such hits or not depending on its boxes.
 template<bool SPH>
 __device__ __forceinline__ bool tri_test_near(const float4 *tris, uint32_t idx, const LaneRay &r, float max_t, float near_rel,
                                               float &t, float &by, float &bz, uint32_t &flat, bool &near) {
@@ -523,9 +544,15 @@ __device__ __forceinline__ bool tri_test_near(const float4 *tris, uint32_t idx, 
     const float b0 = near_rel * fabsf(h.t0), b1 = near_rel * fabsf(h.t1);
     near = h.geometric && (fabsf(h.t0 - max_t) <= b0 || fabsf(h.t0 - r.min_t) <= b0 ||
                            fabsf(h.t1 - max_t) <= b1 || fabsf(h.t1 - r.min_t) <= b1);
-    return h.cand && !(h.t > max_t);
+    const bool accept = h.cand && !(h.t > max_t);
+    if (accept) {                                         // get_bbox (primitives.cuh:166-169): origin -/+ (r, r, r)
+      const V3 c = mk(q0.x, q0.y, q0.z), rr = mk(q0.w, q0.w, q0.w);
+      near = near || !own_box_admits(vsub(c, rr), vadd(c, rr), r, t);
+    }
+    return accept;
   }
-  const V3 p1 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
+  const V3 p1 = mk(q0.x, q0.y, q0.z), p2 = mk(q0.w, q1.x, q1.y), p3 = mk(q1.z, q1.w, q2.x);
+  const V3 e1 = vsub(p2, p1), e2 = vsub(p3, p1);          // primitives.cuh:138-139
   const V3 s = vsub(r.o, p1);
   const V3 s1 = vcross(r.d, e2);
   const V3 s2 = vcross(s, e1);
@@ -536,18 +563,13 @@ __device__ __forceinline__ bool tri_test_near(const float4 *tris, uint32_t idx, 
   const float bx = 1 - by - bz;
   const bool inside = !(t < 0 || bx < 0 || by < 0 || bz < 0);
   const float band = near_rel * fabsf(t);                 // t finite here or the comparisons below are false / handled by the caller
-  // Second reason to hand a ray over: the hit lies within EDGE_EPS * t of a vertex, or of an edge that runs close to a
-  // coordinate axis.  Only there can the hit point sit on an EDGE of a reference node box (the box contains the triangle,
-  // so its edges touch it in vertices or along such edges), where the reference's slab test has entry ~ exit and can lose
-  // the hit to rounding - whatever the neighbouring triangles do.  b_i * hmin <= distance to the edge opposite vertex i.
-  constexpr float EDGE_EPS = 4.0e-6f;
-  const uint32_t w11 = f2u(q2.w);
-  const float hmin = u2f(w11 & ~7u), eband = EDGE_EPS * fabsf(t);
-  const float bmax = fmaxf(bx, fmaxf(by, bz));
-  const bool at_rim = ((1.0f - bmax) * hmin <= eband) || ((w11 & 1u) && bz * hmin <= eband) ||
-                      ((w11 & 2u) && by * hmin <= eband) || ((w11 & 4u) && bx * hmin <= eband);
+  near = inside && (fabsf(t - max_t) <= band || fabsf(t - r.min_t) <= band);
   const bool accept = inside && !(t <= r.min_t || t > max_t);
-  near = (inside && (fabsf(t - max_t) <= band || fabsf(t - r.min_t) <= band)) || (accept && at_rim);
+  if (accept) {                                           // get_bbox (primitives.cuh:170-175): min / max of the three vertices
+    const V3 lo = mk(fminf(p1.x, fminf(p2.x, p3.x)), fminf(p1.y, fminf(p2.y, p3.y)), fminf(p1.z, fminf(p2.z, p3.z)));
+    const V3 hi = mk(fmaxf(p1.x, fmaxf(p2.x, p3.x)), fmaxf(p1.y, fmaxf(p2.y, p3.y)), fmaxf(p1.z, fmaxf(p2.z, p3.z)));
+    near = near || !own_box_admits(lo, hi, r, t);
+  }
   return accept;
 }
 
