@@ -15,7 +15,7 @@ SYMBOLS = [
     "mirt_scene_create_opts", "mirt_scene_destroy", "mirt_scene_build_times", "mirt_scene_own_tree",
     "mirt_scene_info", "mirt_scene_bvh2", "mirt_camera_look_at", "mirt_render", "mirt_render_accum", "mirt_tonemap",
     "mirt_primary_hits", "mirt_trace", "mirt_save_bmp", "mirt_tonemap_host", "mirt_bvh_build_host",
-    "mirt_bvh_build_host_prims",
+    "mirt_bvh_build_host_prims", "mirt_trace_static",
 ]
 
 
@@ -284,6 +284,15 @@ class Scene:
         _chk(load().mirt_trace(self.h, _p(rays8), C.c_uint32(n), C.c_int(int(anyhit)), C.c_uint32(traversal), _p(idx),
                                _p(tb), _p(b)))
         return (idx, tb, b) if bary else (idx, tb)
+
+
+TRACE_STATIC_MAX_RAYS = 65536
+
+
+def trace_static(scene, rays_ptr, n, idx_ptr, tbits_ptr, anyhit=False, traversal=0):
+    """mirt_trace_static: device pointers in and out (integers, e.g. torch tensor .data_ptr()), no allocation inside."""
+    _chk(load().mirt_trace_static(scene.h, C.c_void_p(rays_ptr), C.c_uint32(n), C.c_int(int(anyhit)), C.c_uint32(traversal),
+                                  C.c_void_p(idx_ptr), C.c_void_p(tbits_ptr)))
 
 
 def bvh_build_host(pos, leaf_size=4, ptype=None):

@@ -115,7 +115,29 @@ enum {
   CTRL_WORDS = CTRL_ERR + CTR_STRIDE
 };
 
+// ---- mirt_trace_static: everything its kernels need beyond the caller's inputs and outputs lives in ONE file-scope device
+// array (each GPU the library runs on holds its own copy until the process ends).  Host code never uses the array's
+// name as an address: mirt_init asks the runtime for the address on the current device (hipGetSymbolAddress) and keeps it.
+constexpr uint32_t STATIC_MAX_RAYS = MIRT_TRACE_STATIC_MAX_RAYS;
+constexpr uint32_t STATIC_GRID = 128;                                    // workgroups of its traversal launches
+constexpr uint32_t STATIC_OVF_DEPTH = 72;                                // stack entries per lane beyond the LDS part
+constexpr size_t align256(size_t v) { return (v + 255) & ~(size_t) 255; }
+constexpr size_t SO_CTRL = 0;
+constexpr size_t SO_RAY_O = align256(SO_CTRL + CTRL_WORDS * 4);
+constexpr size_t SO_RAY_D = SO_RAY_O + (size_t) STATIC_MAX_RAYS * 16;
+constexpr size_t SO_HIT = SO_RAY_D + (size_t) STATIC_MAX_RAYS * 16;
+constexpr size_t SO_OCC = SO_HIT + (size_t) STATIC_MAX_RAYS * 16;
+constexpr size_t SO_ANY_T = SO_OCC + (size_t) STATIC_MAX_RAYS * 4;
+constexpr size_t SO_QUEUE = SO_ANY_T + (size_t) STATIC_MAX_RAYS * 4;
+constexpr size_t SO_REDO = SO_QUEUE + (size_t) STATIC_MAX_RAYS * 4;
+constexpr size_t SO_OVF = SO_REDO + (size_t) STATIC_MAX_RAYS * 4;
+constexpr size_t SCRATCH_BYTES = SO_OVF + (size_t) STATIC_OVF_DEPTH * STATIC_GRID * TRACE_BLOCK * sizeof(uint2);   // ~ 23 MB
+constexpr int MAX_DEVICES = 64;
+unsigned char *g_scratch_ptr[MAX_DEVICES] = {};                          // per device: its copy's address
+
 }  // namespace
+
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 
 struct mirt_scene {
   HostBVH bvh;
@@ -176,6 +198,11 @@ int mirt_init(int device) {
   }
   G.stream = G.pstream[0];
   G.side = G.pside[0];
+  if (device < MAX_DEVICES && !g_scratch_ptr[device]) {
+    void *ptr = nullptr;
+    HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));               // this device's copy (hipSetDevice above)
+    g_scratch_ptr[device] = (unsigned char *) ptr;
+  }
   G.table_exact = build_tonemap_table(G.table);
   HIPCHK(G.d_table.ensure(sizeof(G.table)));
   HIPCHK(hipMemcpy(G.d_table.p, G.table, sizeof(G.table), hipMemcpyHostToDevice));
@@ -655,9 +682,10 @@ TraceArgs shadow_args(mirt_scene *s, uint32_t traversal, int pipe = 0, size_t ko
 
 // One trace launch plus the reference walk over the rays it set aside, on `stream`.
 int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, std::vector<Timed> *timed, bool count,
-              hipStream_t stream, uint32_t blocks_per_cu = 0) {
+              hipStream_t stream, uint32_t blocks_per_cu = 0, uint32_t grid_cap = 0) {
   uint32_t grid = s->trace_threads / TRACE_BLOCK;                       // what the overflow regions are sized for
   if (blocks_per_cu && blocks_per_cu * (uint32_t) G.n_cu < grid) grid = blocks_per_cu * (uint32_t) G.n_cu;
+  if (grid_cap && grid_cap < grid) grid = grid_cap;
   Timed tm{any ? 2 : 1, nullptr, nullptr};
   if (timed) {
     tm.a = G.pool_next();
@@ -1128,6 +1156,59 @@ int mirt_trace(mirt_scene *s, const float *rays, uint32_t n, int any_hit, uint32
   uint32_t err = 0;
   HIPCHK(hipMemcpy(&err, ctrl + CTRL_ERR, 4, hipMemcpyDeviceToHost));
   if (err) return fail(MIRT_E_LIMIT, "traversal stack overflow on the device (BVH too deep)");
+  return MIRT_OK;
+}
+
+// mirt_trace for callers that cannot allocate: device in, device out, every intermediate in `scratch`.  No hipMalloc /
+// hipFree / hipHostMalloc, no event or stream creation, no host containers: launches, one memset, one 4-byte copy into the
+// pinned block mirt_init made, one stream synchronisation.
+int mirt_trace_static(mirt_scene *s, const float *rays_dev, uint32_t n, int any_hit, uint32_t traversal, int32_t *idx_dev,
+                      uint32_t *tbits_dev) {
+  if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
+  if (!s || !idx_dev || !tbits_dev) return fail(MIRT_E_ARG, "null argument");
+  if (traversal > 2) return fail(MIRT_E_ARG, "bad traversal");
+  if (n > STATIC_MAX_RAYS)
+    return fail(MIRT_E_LIMIT, "mirt_trace_static: more than MIRT_TRACE_STATIC_MAX_RAYS (65536) rays in one call");
+  if (traversal == 0 && !s->fast_ok) traversal = 1;
+  if (traversal != 2 && s->ovf_depth > STATIC_OVF_DEPTH)
+    return fail(MIRT_E_LIMIT, "mirt_trace_static: the scene's tree is too deep for the static stack region (72 entries per "
+                              "lane beyond the LDS part); use mirt_trace or traversal 2");
+  unsigned char *base = (G.device >= 0 && G.device < MAX_DEVICES) ? g_scratch_ptr[G.device] : nullptr;
+  if (!base) return fail(MIRT_E_STATE, "mirt_trace_static: no scratch address for this device");
+  if (n == 0) return MIRT_OK;
+  if (!rays_dev) return fail(MIRT_E_ARG, "rays_dev is null");
+  uint32_t *ctrl = (uint32_t *) (base + SO_CTRL);
+  TraceArgs t = common_args(s, traversal);
+  t.ray_o = (const float4 *) (base + SO_RAY_O);
+  t.ray_d = (const float4 *) (base + SO_RAY_D);
+  t.queue = (const uint32_t *) (base + SO_QUEUE);
+  t.qcount = ctrl + CTRL_QCOUNT;
+  t.qc_front = any_hit ? QC_SHADOW : QC_EXT_FRONT;
+  t.qc_back = -1;
+  t.qcap = n;
+  t.hit = (float4 *) (base + SO_HIT);
+  t.occ = (uint32_t *) (base + SO_OCC);
+  t.any_t = any_hit ? (float *) (base + SO_ANY_T) : nullptr;
+  t.work_head = ctrl + CTRL_WORK;
+  t.ovf = (uint2 *) (base + SO_OVF);
+  t.redo_queue = (uint32_t *) (base + SO_REDO);
+  t.redo_count = ctrl + CTRL_REDO;
+  t.error_flag = ctrl + CTRL_ERR;
+  t.redo_stat = nullptr;
+  t.count_stat = nullptr;
+  // the array keeps the last call's contents: the whole control block (counters, work heads, redo count, error flag)
+  // starts at zero; rays, queue and results are rewritten for [0, n) before they are read
+  HIPCHK(hipEventRecord(G.ev_in, nullptr));                              // after the caller's NULL-stream work on its buffers
+  HIPCHK(hipStreamWaitEvent(G.stream, G.ev_in, 0));
+  HIPCHK(hipMemsetAsync(ctrl, 0, CTRL_WORDS * 4, G.stream));
+  HIPCHK(launch_stage_rays(rays_dev, n, (float4 *) (base + SO_RAY_O), (float4 *) (base + SO_RAY_D), (uint32_t *) (base + SO_QUEUE),
+                           ctrl + CTRL_QCOUNT + t.qc_front, G.stream));
+  int rc = run_trace(s, t, any_hit != 0, traversal, nullptr, false, G.stream, 0, STATIC_GRID);
+  if (rc) { (void) hipStreamSynchronize(G.stream); return rc; }
+  HIPCHK(launch_unstage_hits(n, any_hit ? 1 : 0, t.hit, t.occ, t.any_t, idx_dev, tbits_dev, G.stream));
+  HIPCHK(hipMemcpyAsync(G.h_counts, ctrl + CTRL_ERR, 4, hipMemcpyDeviceToHost, G.stream));   // pinned: no staging
+  HIPCHK(hipStreamSynchronize(G.stream));
+  if (G.h_counts[0]) return fail(MIRT_E_LIMIT, "traversal stack overflow on the device (BVH too deep)");
   return MIRT_OK;
 }
 

@@ -1228,6 +1228,32 @@ __global__ void k_iota(uint32_t *q, uint32_t n) {
   if (i < n) q[i] = i;
 }
 
+// mirt_trace_static: the caller's ray records (n x 8 floats, device memory) into the traversal kernels' layout, plus the
+// identity queue and its counter (the control block was cleared before).
+__global__ void k_stage_rays(const float *rays8, uint32_t n, float4 *ray_o, float4 *ray_d, uint32_t *queue, uint32_t *qcount_slot) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *qcount_slot = n;
+  if (i >= n) return;
+  const float4 a = ((const float4 *) rays8)[2 * (size_t) i], b = ((const float4 *) rays8)[2 * (size_t) i + 1];
+  ray_o[i] = make_float4(a.x, a.y, a.z, b.z);           // origin | min_t
+  ray_d[i] = make_float4(a.w, b.x, b.y, b.w);           // ctor direction | max_t
+  queue[i] = i;
+}
+
+__global__ void k_unstage_hits(uint32_t n, int any, const float4 *hit, const uint32_t *occ, const float *any_t, int32_t *idx_out,
+                               uint32_t *tbits_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (any) {
+    idx_out[i] = occ[i] ? 1 : -1;
+    tbits_out[i] = f2u(any_t[i]);
+  } else {
+    const float4 h = hit[i];
+    idx_out[i] = (int32_t) f2u(h.w);
+    tbits_out[i] = f2u(h.x);
+  }
+}
+
 // Sample streams: the per-stream partial sums (sum rgb, sample count) are added in stream order, so the result does not
 // depend on scheduling.
 __global__ void k_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n, float4 *out, int add_to_out) {
@@ -1308,6 +1334,18 @@ hipError_t launch_gather_primary(const RenderArgs &a, int32_t *idx, uint32_t *tb
 hipError_t launch_iota(uint32_t *q, uint32_t n, hipStream_t st) {
   if (n == 0) return hipSuccess;
   k_iota<<<(n + 255) / 256, 256, 0, st>>>(q, n);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_stage_rays(const float *rays8, uint32_t n, float4 *ray_o, float4 *ray_d, uint32_t *queue, uint32_t *qcount_slot,
+                             hipStream_t st) {
+  k_stage_rays<<<(n + 255) / 256, 256, 0, st>>>(rays8, n, ray_o, ray_d, queue, qcount_slot);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_unstage_hits(uint32_t n, int any, const float4 *hit, const uint32_t *occ, const float *any_t, int32_t *idx_out,
+                               uint32_t *tbits_out, hipStream_t st) {
+  k_unstage_hits<<<(n + 255) / 256, 256, 0, st>>>(n, any, hit, occ, any_t, idx_out, tbits_out);
   LAUNCH_CHECK();
   return hipSuccess;
 }

@@ -93,6 +93,11 @@ hipError_t launch_logic(const RenderArgs &a, bool deferred_microfacet, hipStream
 hipError_t launch_probe_primary(const RenderArgs &a, hipStream_t st);
 hipError_t launch_gather_primary(const RenderArgs &a, int32_t *idx, uint32_t *tb, hipStream_t st);
 hipError_t launch_iota(uint32_t *q, uint32_t n, hipStream_t st);
+// mirt_trace_static: caller's n x 8 ray records (device) -> ray_o / ray_d / identity queue / queue counter, and back
+hipError_t launch_stage_rays(const float *rays8, uint32_t n, float4 *ray_o, float4 *ray_d, uint32_t *queue, uint32_t *qcount_slot,
+                             hipStream_t st);
+hipError_t launch_unstage_hits(uint32_t n, int any, const float4 *hit, const uint32_t *occ, const float *any_t, int32_t *idx_out,
+                               uint32_t *tbits_out, hipStream_t st);
 hipError_t launch_sum_planes(const float4 *planes, uint32_t n_planes, uint32_t n, float4 *out, int add_to_out, hipStream_t st);
 hipError_t launch_tonemap(const void *accum, uint32_t n, const float *table, uint32_t *rgb /* r | g << 8 | b << 16 */, hipStream_t st);
 hipError_t launch_trace(const TraceArgs &a, bool any, uint32_t traversal, uint32_t grid_blocks, hipStream_t st);
