@@ -148,13 +148,10 @@ def main():
     # the timed steps carry HIP events around the dominant kernel's launches only (every event pair costs a little)
     opt = dict(rng_mode=args.rng, traversal=args.traversal, profile_closest=True, streams=args.streams if args.rng == 1 else 0,
                cull_zero=args.cull_zero)
-    if world > 1 and args.partition == "tile":
-        opt.update(tile_rank=rank, tile_world=world)
-    elif world > 1:
-        if args.spp < world:
-            raise SystemExit("spp partition needs at least one sample per rank: use --partition tile")
-        per = args.spp // world
-        opt.update(rng_mode=1, sample_begin=rank * per, sample_count=per if rank < world - 1 else args.spp - per * (world - 1))
+    from raytracer_amd import dist as rdist
+
+    if world > 1 and args.partition == "spp" and args.spp < world:
+        raise SystemExit("spp partition needs at least one sample per rank: use --partition tile")
     kw = dict(spp=args.spp, spl=1, batch=args.spp + 1, tol=0.0, depth=args.depth)   # fixed spp: no adaptive stop
 
     def barrier():
@@ -164,16 +161,12 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        st = scene.render_accum(w, h, accum.data_ptr(), **kw, **opt)
-        if dist is not None and args.backend == "nccl":
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        # the one N > 1 code path (raytracer_amd/dist.py, rehearsed with gloo in tests/test_dist_cpu.py): partition options
+        # for this rank -> libmirt -> ONE sum-reduce of the accumulation buffer onto rank 0
+        st = rdist.render_partitioned(lambda acc, **part: scene.render_accum(w, h, acc.data_ptr(), **kw, **{**opt, **part}),
+                                      accum, dist, rank, world, args.partition, args.spp, via_host=args.backend == "gloo")
+        if dist is not None:
             torch.cuda.synchronize()
-        elif dist is not None:
-            host = accum.cpu()
-            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0:
-                accum.copy_(host)
-                torch.cuda.synchronize()
         if rank == 0:
             capi.tonemap(accum.data_ptr(), w, h)          # film in host memory
         return st
@@ -232,6 +225,7 @@ def main():
                                    f"{len(sd.lights)} light{'s' if len(sd.lights) != 1 else ''}, rng {'counter' if opt['rng_mode'] else 'xorshift'}, "
                                    f"traversal {args.traversal}, {opt['streams']} sample streams",
                        "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
+                       "reference_walk_rays_per_frame": sum(s["exact_fallback_rays"] for s in stats) / max(1, args.steps),
                        "scene_build_s": build_s, "builder": args.builder or "host", "build_ms": build_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_per_launch(args, world),

@@ -148,14 +148,14 @@ struct mirt_scene {
   uint32_t own_builder = 0;              // 0 host binned SAH, 1 device (build.hip)
   uint32_t n_nodes8 = 0, depth8 = 0;
   float build_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big, trisf, nodes8q;
+  DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big, trisf, nodes8q, verts;
   uint32_t ovf_depth = 0;
   uint32_t trace_threads = 0;
   // work buffers (sized per render)
   DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2], mf_queue, live[2];
   DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t, planes;
   size_t device_bytes() const {
-    const DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
+    const DevBuf *all[] = {&verts, &nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                            &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0],
                            &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue, &planes, &live[0], &live[1]};
     size_t s = 0;
@@ -163,7 +163,7 @@ struct mirt_scene {
     return s;
   }
   void release_all() {
-    DevBuf *all[] = {&nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
+    DevBuf *all[] = {&verts, &nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                      &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0], &redo_q[1],
                      &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue, &planes, &live[0], &live[1]};
     for (auto *b: all) b->release();
@@ -347,7 +347,7 @@ static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const u
   s->n_mats = n_mats;
   s->n_lights = n_lights;
 
-  // triangles in the reference's flat order: (p1, p2, p3) for the intersector, (n1, n2, n3, material, original id) for shading
+  // triangles in the reference's flat order: (p1, e1, e2) for the intersector, (n1, n2, n3, material, original id) for shading
   std::vector<float> tri((size_t) n_tris * 12), nrm((size_t) n_tris * 12);
   std::atomic<bool> sphere_seen{false};
   parallel_for(n_tris, [&](size_t f0, size_t f1) {
@@ -365,9 +365,9 @@ static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const u
       memset(m, 0, 9 * sizeof(float));
       m[0] = p[0]; m[1] = p[1]; m[2] = p[2];
     } else {
-      // p1 p2 p3 as given: the intersector forms e1 = p2 - p1, e2 = p3 - p1 itself (primitives.cuh:138-139), and the ordered
-      // traversal needs the exact vertices for the primitive's own bounding box (kernels.hip tri_test_near)
-      memcpy(t, p, 9 * sizeof(float));
+      t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
+      t[3] = p[3] - p[0]; t[4] = p[4] - p[1]; t[5] = p[5] - p[2];     // e1 = p2 - p1 (primitives.cuh:138)
+      t[6] = p[6] - p[0]; t[7] = p[7] - p[1]; t[8] = p[8] - p[2];     // e2 = p3 - p1 (primitives.cuh:139)
       memcpy(m, q, 9 * sizeof(float));
     }
     memcpy(t + 9, &f, 4);                                             // its own flat index (uniform with the fast tree's copy)
@@ -427,6 +427,7 @@ static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const u
             up(s->nodes4, s->bvh.nodes4.data(), s->bvh.nodes4.size() * sizeof(Node4)) &&
             up(s->nodes2, s->bvh.nodes2.data(), s->bvh.nodes2.size() * sizeof(Node2)) &&
             up(s->mats, mats_padded.data(), mats_padded.size() * 4) &&
+            up(s->verts, flat_pos.data(), flat_pos.size() * 4) &&          // exact vertices, flat order (rare path of tri_test_near)
             up(s->big, s->bvh.big.empty() ? (const void *) mats : (const void *) s->bvh.big.data(), s->bvh.big.empty() ? 8 : s->bvh.big.size() * 4) &&
             up(s->lights, lights ? (const void *) lights : (const void *) mats, n_lights ? (size_t) n_lights * sizeof(mirt_light) : 4);
   if (ok && builder == 0)
@@ -631,6 +632,7 @@ TraceArgs common_args(mirt_scene *s, uint32_t traversal) {
   t.tris2 = s->tris.as<float4>();
   t.require_unit = traversal == 0 ? 1 : 0;
   t.nodes8 = s->nodes8q.p;
+  t.verts = s->verts.as<float>();
   t.spheres = s->has_spheres ? 1 : 0;
   t.refill_min = G.refill_min;
   t.static_16th = G.static_16th;

@@ -485,7 +485,7 @@ __device__ __forceinline__ SphereHit sphere_eval(const float4 q0, const float4 q
   return h;
 }
 
-// Moeller-Trumbore exactly as primitives.cuh:137-158 evaluates it (the record holds p1 p2 p3).
+// Moeller-Trumbore exactly as primitives.cuh:137-158 evaluates it (e1, e2 are stored: same subtraction, same bits).
 // Returns the reference's accept decision against `max_t`.  Word 10 of the record: 0 triangle, 1 sphere.
 __device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const LaneRay &r, float max_t, float &t,
                                          float &by, float &bz, uint32_t &flat) {
@@ -496,8 +496,7 @@ __device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const
     t = h.t; by = 0.f; bz = 0.f;
     return h.cand && !(h.t > max_t);
   }
-  const V3 p1 = mk(q0.x, q0.y, q0.z), p2 = mk(q0.w, q1.x, q1.y), p3 = mk(q1.z, q1.w, q2.x);
-  const V3 e1 = vsub(p2, p1), e2 = vsub(p3, p1);          // primitives.cuh:138-139
+  const V3 p1 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
   const V3 s = vsub(r.o, p1);
   const V3 s1 = vcross(r.d, e2);
   const V3 s2 = vcross(s, e1);
@@ -509,19 +508,22 @@ __device__ __forceinline__ bool tri_test(const float4 *tris, uint32_t idx, const
   return !(t < 0 || t <= r.min_t || t > max_t || bx < 0 || by < 0 || bz < 0);
 }
 
-// The reference's slab test (bbox.cuh:67-79) of the ray against the primitive's OWN bounding box [lo, hi], with the hit
-// distance standing in for max_t.  Every box of the reference's tree above the primitive contains this box, and the slab
-// arithmetic is monotone in the box bounds (lo' <= lo gives (lo' - o) * inv on the same side of (lo - o) * inv, rounding
-// included), so when this test passes every one of them passes too - whatever the reference's tree looks like - and the
-// reference reaches the primitive and takes the same decision on it.  (Finite operands only: the caller has set aside
-// rays with zero / non-finite components, for which the min/max chains below equal the reference's std::max/std::min.)
-__device__ __forceinline__ bool own_box_admits(const V3 lo, const V3 hi, const LaneRay &r, float t_hit) {
+// The reference's slab arithmetic (bbox.cuh:67-79) on the primitive's OWN bounding box [lo, hi].  Every box of the
+// reference's tree above the primitive contains this box, and the slab arithmetic is monotone in the box bounds (lo' <= lo
+// puts (lo' - o) * inv on the outer side of (lo - o) * inv, rounding included): their entry distances are <= this box's
+// entry E, their exit distances >= its exit X - whatever the reference's tree looks like.  The reference tests them with
+// tmax = min(exit, m), m = its max_t at that moment, and m >= t_hit when the hit is the nearest one.  So it reaches the
+// primitive (and takes the same decision on it) if  E <= X,  X > min_t  and  E <= m.  The last holds when
+// E <= t_hit * (1 + NEAR): an m below that is a hit within NEAR of this one, a tie the caller flags anyway.
+// (Finite operands only: the caller has set aside rays with zero / non-finite components, for which the min/max chains
+// below equal the reference's std::max/std::min.)
+__device__ __forceinline__ bool own_box_admits(const V3 lo, const V3 hi, const LaneRay &r, float t_limit) {
   const float ax = (lo.x - r.o.x) * r.inv.x, bx = (hi.x - r.o.x) * r.inv.x;
   const float ay = (lo.y - r.o.y) * r.inv.y, by = (hi.y - r.o.y) * r.inv.y;
   const float az = (lo.z - r.o.z) * r.inv.z, bz = (hi.z - r.o.z) * r.inv.z;
   const float tmn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-  const float tmx = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t_hit));
-  return tmn <= tmx && tmx > r.min_t;
+  const float tmx = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  return tmn <= tmx && tmx > r.min_t && tmn <= t_limit;
 }
 
 // The ordered traversal's variant: same arithmetic and accept decision, plus `near` = "the reference's outcome for this
@@ -534,8 +536,8 @@ __device__ __forceinline__ bool own_box_admits(const V3 lo, const V3 hi, const L
 //     "hit" that Moeller-Trumbore reports from outside the triangle (its barycentrics are ill-conditioned when the ray runs
 //     almost in the triangle's plane).  The reference finds such hits or not depending on its boxes.
 template<bool SPH>
-__device__ __forceinline__ bool tri_test_near(const float4 *tris, uint32_t idx, const LaneRay &r, float max_t, float near_rel,
-                                              float &t, float &by, float &bz, uint32_t &flat, bool &near) {
+__device__ __forceinline__ bool tri_test_near(const float4 *tris, const float *verts, uint32_t idx, const LaneRay &r, float max_t,
+                                              float near_rel, float &t, float &by, float &bz, uint32_t &flat, bool &near) {
   const float4 q0 = tris[3 * (size_t) idx], q1 = tris[3 * (size_t) idx + 1], q2 = tris[3 * (size_t) idx + 2];
   flat = f2u(q2.y);
   if (SPH && f2u(q2.z) != 0u) {
@@ -547,12 +549,11 @@ __device__ __forceinline__ bool tri_test_near(const float4 *tris, uint32_t idx, 
     const bool accept = h.cand && !(h.t > max_t);
     if (accept) {                                         // get_bbox (primitives.cuh:166-169): origin -/+ (r, r, r)
       const V3 c = mk(q0.x, q0.y, q0.z), rr = mk(q0.w, q0.w, q0.w);
-      near = near || !own_box_admits(vsub(c, rr), vadd(c, rr), r, t);
+      near = near || !own_box_admits(vsub(c, rr), vadd(c, rr), r, t * (1.0f + near_rel));
     }
     return accept;
   }
-  const V3 p1 = mk(q0.x, q0.y, q0.z), p2 = mk(q0.w, q1.x, q1.y), p3 = mk(q1.z, q1.w, q2.x);
-  const V3 e1 = vsub(p2, p1), e2 = vsub(p3, p1);          // primitives.cuh:138-139
+  const V3 p1 = mk(q0.x, q0.y, q0.z), e1 = mk(q0.w, q1.x, q1.y), e2 = mk(q1.z, q1.w, q2.x);
   const V3 s = vsub(r.o, p1);
   const V3 s1 = vcross(r.d, e2);
   const V3 s2 = vcross(s, e1);
@@ -565,10 +566,44 @@ __device__ __forceinline__ bool tri_test_near(const float4 *tris, uint32_t idx, 
   const float band = near_rel * fabsf(t);                 // t finite here or the comparisons below are false / handled by the caller
   near = inside && (fabsf(t - max_t) <= band || fabsf(t - r.min_t) <= band);
   const bool accept = inside && !(t <= r.min_t || t > max_t);
-  if (accept) {                                           // get_bbox (primitives.cuh:170-175): min / max of the three vertices
-    const V3 lo = mk(fminf(p1.x, fminf(p2.x, p3.x)), fminf(p1.y, fminf(p2.y, p3.y)), fminf(p1.z, fminf(p2.z, p3.z)));
-    const V3 hi = mk(fmaxf(p1.x, fmaxf(p2.x, p3.x)), fmaxf(p1.y, fmaxf(p2.y, p3.y)), fmaxf(p1.z, fmaxf(p2.z, p3.z)));
-    near = near || !own_box_admits(lo, hi, r, t);
+  // Own-box admission, in three steps of rising cost and falling frequency.
+  // 1. The hit lies well inside the triangle - every barycentric above ADMIT_K * (|t| + L) * L / |det| (L = upper bound of the
+  //    edge lengths; |det| = 2 * area * |cos incidence|), i.e. at least ~1e-5 * t / |cos| away from every edge, some 25
+  //    times what the slab arithmetic and the conditioning of the barycentrics can move it: the ray passes through the
+  //    interior of the triangle's box with room to spare.  ~98 % of the hits stop here.
+  // 2. own_box_admits on a box that is CONTAINED in the exact one: the box of p1, p1 + e1, p1 + e2 (each within 1.5 ulp of the
+  //    exact vertex) shrunk by 4e-7 relative per side, except along axes in which the triangle is exactly flat (e1 = e2 = 0
+  //    there: the coordinate is exact).  Monotonicity again: what the smaller box admits, the exact one admits.
+  // 3. Otherwise (a hit on the rim of the box; an axis too thin to shrink): the exact vertices from memory.
+#ifndef MIRT_ADMIT_K
+#define MIRT_ADMIT_K 1.0e-5f
+#endif
+  constexpr float ADMIT_K = MIRT_ADMIT_K;
+  const float L = fabsf(e1.x) + fabsf(e1.y) + fabsf(e1.z) + fabsf(e2.x) + fabsf(e2.y) + fabsf(e2.z);   // >= every edge length
+#ifndef MIRT_ADMIT_LEVEL
+#define MIRT_ADMIT_LEVEL 3
+#endif
+#if MIRT_ADMIT_LEVEL == 0
+  if (false) {
+#else
+  if (__builtin_expect(accept && !(fminf(bx, fminf(by, bz)) > (ADMIT_K * fabsf(rc)) * ((fabsf(t) + L) * L)), 0)) {
+#endif
+    const V3 vb = vadd(p1, e1), vc = vadd(p1, e2);
+    V3 lo = mk(fminf(p1.x, fminf(vb.x, vc.x)), fminf(p1.y, fminf(vb.y, vc.y)), fminf(p1.z, fminf(vb.z, vc.z)));
+    V3 hi = mk(fmaxf(p1.x, fmaxf(vb.x, vc.x)), fmaxf(p1.y, fmaxf(vb.y, vc.y)), fmaxf(p1.z, fmaxf(vb.z, vc.z)));
+    const float ux = (e1.x == 0.f && e2.x == 0.f) ? 0.f : 4.0e-7f * fmaxf(fabsf(lo.x), fabsf(hi.x));
+    const float uy = (e1.y == 0.f && e2.y == 0.f) ? 0.f : 4.0e-7f * fmaxf(fabsf(lo.y), fabsf(hi.y));
+    const float uz = (e1.z == 0.f && e2.z == 0.f) ? 0.f : 4.0e-7f * fmaxf(fabsf(lo.z), fabsf(hi.z));
+    lo = mk(lo.x + ux, lo.y + uy, lo.z + uz);
+    hi = mk(hi.x - ux, hi.y - uy, hi.z - uz);
+    const float t_limit = t * (1.0f + near_rel);
+    if (!(lo.x <= hi.x && lo.y <= hi.y && lo.z <= hi.z && own_box_admits(lo, hi, r, t_limit))) {
+      const float *v = verts + 9 * (size_t) flat;         // get_bbox (primitives.cuh:170-175): min / max of the exact vertices
+      const V3 a = mk(v[0], v[1], v[2]), b = mk(v[3], v[4], v[5]), c = mk(v[6], v[7], v[8]);
+      lo = mk(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)));
+      hi = mk(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)));
+      near = near || !own_box_admits(lo, hi, r, t_limit);
+    }
   }
   return accept;
 }
@@ -1135,7 +1170,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
         n_tris++;
         if (lane_rank(__ballot(1)) == 0) n_tri_steps++;
       }
-      const bool acc = tri_test_near<SPH>(a.tris, tri_i, r, r.best_t, NEAR, t, by, bz, flat, near);
+      const bool acc = tri_test_near<SPH>(a.tris, a.verts, tri_i, r, r.best_t, NEAR, t, by, bz, flat, near);
       tri_i++;
       tri_n--;
       if (near || (acc && !(fabsf(t) < MIRT_INF))) {

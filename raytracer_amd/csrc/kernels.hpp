@@ -68,6 +68,7 @@ struct TraceArgs {
   const float4 *nodes2;                   // 2 float4 per reference node
   const float4 *tris;                     // triangles in the order of the tree k_trace4 walks: p1, e1, e2, flat index
   const float4 *tris2;                    // triangles in the reference's flat order (k_trace2)
+  const float *verts;                     // 9 floats per primitive, flat order: the exact p1 p2 p3 (own-box test of k_trace_fast)
   const uint2 *big;                       // (start, count) of leaves with more than 15 primitives
   const float4 *ray_o, *ray_d;
   const uint32_t *queue, *qcount;

@@ -23,7 +23,10 @@ def tile_owner(width, height, world):
 
 
 def spp_slices(spp, world):
-    """[(begin, count)] per rank; the last rank takes the remainder.  Ranks with count 0 render nothing."""
+    """[(begin, count)] per rank; the last rank takes the remainder.  Needs at least one sample per rank: libmirt reads
+    sample_count == 0 as "all samples" (mirt.h), so an empty slice cannot be expressed."""
+    if world < 1 or spp < world:
+        raise ValueError(f"spp partition needs at least one sample per rank ({spp} spp, {world} ranks): use the tile partition")
     per = spp // world
     out = []
     for r in range(world):
@@ -38,11 +41,31 @@ def partition_options(kind, rank, world, spp):
         return {}
     if kind == "tile":
         return dict(tile_rank=rank, tile_world=world)
+    if kind != "spp":
+        raise ValueError(f"unknown partition {kind!r}")
     begin, count = spp_slices(spp, world)[rank]
     return dict(rng_mode=1, sample_begin=begin, sample_count=count)
 
 
-def reduce_accum(accum, dist, dst=0):
-    """Sum the per-rank accumulation buffers onto `dst` (RCCL reduce on GPUs; gloo in the CPU tests)."""
-    dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+def reduce_accum(accum, dist, dst=0, via_host=False):
+    """The frame's ONE collective: sum the per-rank accumulation buffers onto `dst` (RCCL reduce on GPUs; gloo in the CPU
+    tests).  via_host: the ranks share GPUs (rehearsal on a box with fewer GPUs than ranks), so the buffers travel through
+    host memory and gloo."""
+    if via_host:
+        host = accum.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+        if dist.get_rank() == dst:
+            accum.copy_(host)
+    else:
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum
+
+
+def render_partitioned(render_accum, accum, dist, rank, world, kind, spp, via_host=False):
+    """One frame over `world` ranks -- the N > 1 path of bench.py and of tests/test_dist_cpu.py: this rank renders its
+    partition into `accum` (`render_accum(accum, **partition_options)` -> stats; pixels / samples it does not own contribute
+    zeros), then the buffers are summed onto rank 0.  Returns the rank's stats."""
+    stats = render_accum(accum, **partition_options(kind, rank, world, spp))
+    if world > 1:
+        reduce_accum(accum, dist, dst=0, via_host=via_host)
+    return stats

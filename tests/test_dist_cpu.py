@@ -34,15 +34,21 @@ def _worker(rank, world, port, kind, out_path):
     w, h, spp, depth = 40, 24, 6, 3
     o = CpuTracer("oracle").load(scenes.cornell_scene(1, "diffuse"))
     o.set_rng(1, 11)
-    opts = rdist.partition_options(kind, rank, world, spp)
-    if kind == "tile":
-        _, acc = o.render(w, h, spp=spp, batch=spp + 1, depth=depth, accum=True)
-        acc = acc * (rdist.tile_owner(w, h, world) == opts["tile_rank"])[..., None]       # zeros elsewhere, like libmirt
-    else:
-        _, acc = o.render(w, h, spp=opts["sample_count"], batch=spp + 1, depth=depth, accum=True,
-                          sample_begin=opts["sample_begin"])
-    t = torch.from_numpy(np.ascontiguousarray(acc))
-    rdist.reduce_accum(t, dist, dst=0)
+
+    def render_accum(buf, **opts):
+        """Stub renderer with libmirt's partition semantics (the C oracle in counter-RNG mode; on GPUs this is
+        capi.Scene.render_accum): writes this rank's share into `buf`, zeros elsewhere."""
+        if "tile_rank" in opts:
+            _, acc = o.render(w, h, spp=spp, batch=spp + 1, depth=depth, accum=True)
+            acc = acc * (rdist.tile_owner(w, h, opts["tile_world"]) == opts["tile_rank"])[..., None]
+        else:
+            _, acc = o.render(w, h, spp=opts["sample_count"], batch=spp + 1, depth=depth, accum=True,
+                              sample_begin=opts["sample_begin"])
+        buf.copy_(torch.from_numpy(np.ascontiguousarray(acc)))
+        return dict(o.last)
+
+    t = torch.zeros((h, w, 4), dtype=torch.float32)
+    rdist.render_partitioned(render_accum, t, dist, rank, world, kind, spp)      # the function bench.py calls
     if rank == 0:
         np.save(out_path, t.numpy())
     dist.barrier()
@@ -73,7 +79,12 @@ def test_partition_helpers():
     own = rdist.tile_owner(20, 17, 3)
     assert own.shape == (17, 20) and set(np.unique(own)) == {0, 1, 2}
     assert (own[:8, :8] == 0).all() and (own[:8, 8:16] == 1).all() and (own[8:16, :8] == (3 % 3)).all()
-    for spp, world in [(64, 8), (7, 3), (2, 4)]:
+    with pytest.raises(ValueError):
+        rdist.spp_slices(2, 4)                                       # an empty slice would mean "all samples" to libmirt
+    with pytest.raises(ValueError):
+        rdist.partition_options("spp", 0, 4, 2)
+    assert rdist.partition_options("spp", 1, 1, 64) == {}
+    for spp, world in [(64, 8), (7, 3), (4, 4)]:
         sl = rdist.spp_slices(spp, world)
         assert sum(c for _, c in sl) == spp and sl[0][0] == 0
         assert all(sl[i][0] + sl[i][1] == sl[i + 1][0] for i in range(world - 1))
