@@ -85,7 +85,9 @@ struct Global {
   uint32_t *h_film = nullptr;            // pinned: the packed film on its way to the caller
   size_t h_film_words = 0;
   hipEvent_t film_ev[8] = {};
-  uint32_t *h_counts = nullptr;          // pinned: 2 pipes x RING x QC_WORDS
+  uint32_t *h_counts = nullptr;          // host-mapped, coherent: MAX_PIPES x RING slots of HSLOT words, written by k_logic
+  uint32_t *d_counts = nullptr;          // the same memory as the device sees it
+  uint32_t seq = 0;                      // stamp of the last iteration issued (never 0)
   hipEvent_t ring_ev[MAX_PIPES][RING] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;    // first launch / accumulation buffer complete (render_ms)
   hipEvent_t ev_in = nullptr;               // entry: recorded on the caller's NULL stream, waited for by `stream`
@@ -105,7 +107,8 @@ struct Timed { int kind; hipEvent_t a, b; };   // kind 0 logic, 1 closest trace,
 
 // control block layout (uint32 words, every counter on a 128-byte line of its own, see kernels.hpp):
 // queue counters | fetch counters of the closest launch | of the shadow launch | redo counts | deferred-microfacet
-// count | error flag.  Everything before the error flag is cleared at the top of every iteration.
+// count | error flag.  Everything before the error flag is cleared for every iteration - by k_logic of
+// the iteration before (three blocks rotate per pipe), not by a memset dispatch.
 enum {
   CTRL_QCOUNT = 0,
   CTRL_WORK = QC_WORDS,
@@ -114,6 +117,8 @@ enum {
   CTRL_ERR = CTRL_MF + CTR_STRIDE,
   CTRL_WORDS = CTRL_ERR + CTR_STRIDE
 };
+constexpr int CTRL_BLOCKS = 3;                           // per pipe: iteration i uses block i % 3 and clears block (i + 1) % 3
+constexpr int HSLOT = 8;                                 // words per host ring slot: 5 queue counters, 2 spare, stamp
 
 // ---- mirt_trace_static: everything its kernels need beyond the caller's inputs and outputs lives in ONE file-scope device
 // array (each GPU the library runs on holds its own copy until the process ends).  Host code never uses the array's
@@ -206,7 +211,9 @@ int mirt_init(int device) {
   G.table_exact = build_tonemap_table(G.table);
   HIPCHK(G.d_table.ensure(sizeof(G.table)));
   HIPCHK(hipMemcpy(G.d_table.p, G.table, sizeof(G.table), hipMemcpyHostToDevice));
-  HIPCHK(hipHostMalloc((void **) &G.h_counts, MAX_PIPES * RING * QC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **) &G.h_counts, MAX_PIPES * RING * QC_WORDS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(G.h_counts, 0, MAX_PIPES * RING * QC_WORDS * sizeof(uint32_t));
+  HIPCHK(hipHostGetDevicePointer((void **) &G.d_counts, G.h_counts, 0));
   for (auto &e: G.film_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(hipEventCreate(&G.ev0));
   HIPCHK(hipEventCreate(&G.ev1));
@@ -616,7 +623,7 @@ int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
   HIPCHK(s->mf_queue.ensure(n * 4));
   HIPCHK(s->live[0].ensure(n * 4));
   HIPCHK(s->live[1].ensure(n * 4));
-  HIPCHK(s->ctrl.ensure(2 * MAX_PIPES * CTRL_WORDS * 4));              // pipes x 2 (an iteration uses block `iteration & 1`)
+  HIPCHK(s->ctrl.ensure(CTRL_BLOCKS * MAX_PIPES * CTRL_WORDS * 4));    // per pipe three blocks in rotation
   HIPCHK(s->ray_stats.ensure(MAX_PIPES * 16 * 8));
   return MIRT_OK;
 }
@@ -640,9 +647,9 @@ TraceArgs common_args(mirt_scene *s, uint32_t traversal) {
   t.ovf_depth = s->ovf_depth;
   return t;
 }
-TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal, int pipe = 0, size_t off = 0, int par = 0) {
+TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal, int pipe = 0, size_t off = 0, int par = 0 /* control block */) {
   TraceArgs t = common_args(s, traversal);
-  uint32_t *ctrl = s->ctrl.as<uint32_t>() + (size_t) (2 * pipe + par) * CTRL_WORDS;
+  uint32_t *ctrl = s->ctrl.as<uint32_t>() + (size_t) (CTRL_BLOCKS * pipe + par) * CTRL_WORDS;
   unsigned long long *rs = s->ray_stats.as<unsigned long long>() + (size_t) pipe * 16;
   t.ray_o = s->ray_o.as<float4>() + off;
   t.ray_d = s->ray_d.as<float4>() + off;
@@ -663,7 +670,7 @@ TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal, int 
 }
 TraceArgs shadow_args(mirt_scene *s, uint32_t traversal, int pipe = 0, size_t koff = 0, int par = 0) {
   TraceArgs t = common_args(s, traversal);
-  uint32_t *ctrl = s->ctrl.as<uint32_t>() + (size_t) (2 * pipe + par) * CTRL_WORDS;
+  uint32_t *ctrl = s->ctrl.as<uint32_t>() + (size_t) (CTRL_BLOCKS * pipe + par) * CTRL_WORDS;
   unsigned long long *rs = s->ray_stats.as<unsigned long long>() + (size_t) pipe * 16;
   t.ray_o = s->sh_o.as<float4>() + koff;
   t.ray_d = s->sh_d.as<float4>() + koff;
@@ -796,7 +803,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   if (!accumulate) HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
   if (via_planes) HIPCHK(hipMemsetAsync(s->planes.p, 0, (size_t) streams * w * h * 16, G.stream));
   HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, MAX_PIPES * 128, G.stream));
-  HIPCHK(hipMemsetAsync(s->ctrl.p, 0, 2 * MAX_PIPES * CTRL_WORDS * 4, G.stream));
+  HIPCHK(hipMemsetAsync(s->ctrl.p, 0, CTRL_BLOCKS * MAX_PIPES * CTRL_WORDS * 4, G.stream));
   HIPCHK(hipEventRecord(evA, G.stream));
 
   // Pipes: with at least two sample streams the slots are split into two halves that run as independent wavefront loops
@@ -811,13 +818,16 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     const int v = atoi(e);
     if (v >= 1 && v <= 16) shadow_blocks = (uint32_t) v;
   }
-  // Every pipe has two control blocks and two live-slot lists; iteration i counts into block i & 1 and reads the list the
-  // iteration before it wrote (so clearing a block never races with a reader of the previous one).
+  // Every pipe has three control blocks and two live-slot lists.  Iteration i counts into block i % 3, reads the live count
+  // of block (i - 1) % 3 and the list iteration i - 1 wrote, and its k_logic zeroes block (i + 1) % 3 - last used by
+  // iteration i - 2, whose launches have all finished - for the next iteration: no memset dispatch per iteration.
   struct Pipe {
-    RenderArgs a[2];
-    TraceArgs tc[2], ts[2];
-    uint32_t *ctrl[2];
+    RenderArgs a;                                   // the pipe's share of the slot arrays; per-iteration fields set at launch
+    TraceArgs tc[CTRL_BLOCKS], ts[CTRL_BLOCKS];
+    uint32_t *ctrl[CTRL_BLOCKS];
+    size_t off = 0;
     uint64_t it = 0, accounted = 0;
+    uint32_t stamp[RING] = {};
     bool done = false, tail = false;
   } pipe[MAX_PIPES];
   for (int p = 0; p < n_pipes; p++) {
@@ -825,24 +835,20 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     const uint32_t s_count = streams * (uint32_t) (p + 1) / (uint32_t) n_pipes - s_first;
     const size_t off = (size_t) s_first * part.n_slots, koff = off * (K ? K : 1);
     Pipe &pp = pipe[p];
-    for (int par = 0; par < 2; par++) {
-      RenderArgs &pa = pp.a[par];
-      pp.ctrl[par] = ctrl + (size_t) (2 * p + par) * CTRL_WORDS;
-      pa = a;
-      pa.n_slots = part.n_slots * s_count;
-      pa.stream_first = s_first;
-      pa.st += off; pa.mask += off; pa.total += off; pa.accum += off; pa.dmask += off;
-      pa.ray_o += off; pa.ray_d += off; pa.hit += off;
-      pa.sh_o += koff; pa.sh_d += koff; pa.sh_c += koff; pa.sh_occ += koff;
-      pa.ext_queue += off; pa.sh_queue += koff; pa.mf_queue += off;
-      pa.qcount = pp.ctrl[par] + CTRL_QCOUNT;
-      pa.mf_count = pp.ctrl[par] + CTRL_MF;
-      pa.ray_stats = a.ray_stats + (size_t) p * 16;
-      pa.live_out = s->live[par].as<uint32_t>() + off;
-      pa.live_in = s->live[par ^ 1].as<uint32_t>() + off;
-      pa.live_in_count = ctrl + (size_t) (2 * p + (par ^ 1)) * CTRL_WORDS + CTRL_QCOUNT + QC_LIVE;
-      pp.tc[par] = closest_args(s, pa.n_slots, o.traversal, p, off, par);
-      pp.ts[par] = shadow_args(s, o.traversal, p, koff, par);
+    pp.off = off;
+    RenderArgs &pa = pp.a;
+    pa = a;
+    pa.n_slots = part.n_slots * s_count;
+    pa.stream_first = s_first;
+    pa.st += off; pa.mask += off; pa.total += off; pa.accum += off; pa.dmask += off;
+    pa.ray_o += off; pa.ray_d += off; pa.hit += off;
+    pa.sh_o += koff; pa.sh_d += koff; pa.sh_c += koff; pa.sh_occ += koff;
+    pa.ext_queue += off; pa.sh_queue += koff; pa.mf_queue += off;
+    pa.ray_stats = a.ray_stats + (size_t) p * 16;
+    for (int b = 0; b < CTRL_BLOCKS; b++) {
+      pp.ctrl[b] = ctrl + (size_t) (CTRL_BLOCKS * p + b) * CTRL_WORDS;
+      pp.tc[b] = closest_args(s, pa.n_slots, o.traversal, p, off, b);
+      pp.ts[b] = shadow_args(s, o.traversal, p, koff, b);
     }
   }
   uint32_t iters = 0;
@@ -852,7 +858,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
       HIPCHK(hipEventRecord(G.pipe_ev[0], G.stream));
       for (int p = 1; p < n_pipes; p++) HIPCHK(hipStreamWaitEvent(G.pstream[p], G.pipe_ev[0], 0));
     }
-    for (int p = 0; p < n_pipes; p++) HIPCHK(launch_init(pipe[p].a[0], G.pstream[p]));
+    for (int p = 0; p < n_pipes; p++) HIPCHK(launch_init(pipe[p].a, G.pstream[p]));
     const uint64_t max_iters = (uint64_t) a.spp * ((uint64_t) a.max_depth + 3) + 8;
     bool all_done = false;
     while (!all_done) {
@@ -862,15 +868,24 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
         if (pp.done) continue;
         all_done = false;
         hipStream_t main = G.pstream[p], side = G.pside[p];
-        uint32_t *hcounts = G.h_counts + (size_t) p * RING * QC_WORDS;
+        volatile uint32_t *hcounts = G.h_counts + (size_t) p * RING * HSLOT;
         const uint64_t it = pp.it++;
         if (it >= max_iters + RING) {
           return fail(MIRT_E_DEVICE, "wavefront loop did not terminate");
         }
-        const int par = (int) (it & 1);
-        RenderArgs la = pp.a[par];
-        if (it == 0) la.live_in = nullptr;                               // no list yet: all slots
-        HIPCHK(hipMemsetAsync(pp.ctrl[par], 0, CTRL_ERR * 4, main));     // queue counters, work heads, redo counters
+        const int blk = (int) (it % CTRL_BLOCKS), prev = (int) ((it + CTRL_BLOCKS - 1) % CTRL_BLOCKS),
+                  next = (int) ((it + 1) % CTRL_BLOCKS), par = (int) (it & 1);
+        const int slot = (int) (it % RING);
+        RenderArgs la = pp.a;
+        la.qcount = pp.ctrl[blk] + CTRL_QCOUNT;
+        la.mf_count = pp.ctrl[blk] + CTRL_MF;
+        la.live_out = s->live[par].as<uint32_t>() + pp.off;
+        la.live_in = it ? s->live[par ^ 1].as<uint32_t>() + pp.off : nullptr;      // first iteration: no list yet, all slots
+        la.live_in_count = pp.ctrl[prev] + CTRL_QCOUNT + QC_LIVE;
+        la.clear_next = pp.ctrl[next];
+        la.clear_words = CTRL_ERR;                                       // queue counters, work heads, redo counters
+        if (++G.seq == 0) G.seq = 1;
+        pp.stamp[slot] = G.seq;
         Timed tl{0, nullptr, nullptr};
         if (profile) {
           tl.a = G.pool_next();
@@ -884,23 +899,23 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
           HIPCHK(hipEventRecord(tl.b, main));
           timed.push_back(tl);
         }
-        const int slot = (int) (it % RING);
-        HIPCHK(hipMemcpyAsync(hcounts + slot * QC_WORDS, pp.ctrl[par] + CTRL_QCOUNT, QC_WORDS * 4, hipMemcpyDeviceToHost, main));
-        HIPCHK(hipEventRecord(G.ring_ev[p][slot], main));
         // The two traversals of an iteration are independent: the shadow rays go to the side stream, so the tail of one
         // launch (a few long rays, the GPU mostly idle) is filled by the other.  MIRT_SERIAL=1 keeps one stream.
         const bool fork = K != 0 && !G.serial;
         if (fork) {
           HIPCHK(hipEventRecord(G.fork_ev[p][slot], main));
           HIPCHK(hipStreamWaitEvent(side, G.fork_ev[p][slot], 0));
-          rc = run_trace(s, pp.ts[par], true, o.traversal, profile ? &timed : nullptr, counting, side, shadow_blocks);
+          rc = run_trace(s, pp.ts[blk], true, o.traversal, profile ? &timed : nullptr, counting, side, shadow_blocks);
           if (rc) return rc;
           HIPCHK(hipEventRecord(G.join_ev[p][slot], side));
         }
-        rc = run_trace(s, pp.tc[par], false, o.traversal, profile_closest ? &timed : nullptr, counting, main, pipe_blocks);
+        TraceArgs tc = pp.tc[blk];
+        tc.host_slot = G.d_counts + ((size_t) p * RING + slot) * HSLOT;   // this launch hands the queue counters to the host
+        tc.stamp = pp.stamp[slot];
+        rc = run_trace(s, tc, false, o.traversal, profile_closest ? &timed : nullptr, counting, main, pipe_blocks);
         if (rc) return rc;
         if (K && !fork) {
-          rc = run_trace(s, pp.ts[par], true, o.traversal, profile ? &timed : nullptr, counting, main, pipe_blocks);
+          rc = run_trace(s, pp.ts[blk], true, o.traversal, profile ? &timed : nullptr, counting, main, pipe_blocks);
           if (rc) return rc;
         }
         if (fork) HIPCHK(hipStreamWaitEvent(main, G.join_ev[p][slot], 0));
@@ -912,16 +927,29 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
         const uint64_t upto = pp.tail ? it + 1 : (it + 1 >= RING - 1 ? it + 1 - (RING - 2) : 0);   // account iterations < upto
         while (pp.accounted < upto && !pp.done) {
           const uint64_t old = pp.accounted++;
-          const uint32_t *hc = hcounts + (old % RING) * QC_WORDS;
-          HIPCHK(hipEventSynchronize(G.ring_ev[p][old % RING]));
+          volatile uint32_t *hc = hcounts + (old % RING) * HSLOT;
+          // the closest-hit launch wrote the counters, then the stamp (system-scope release): poll it
+          const uint32_t want = pp.stamp[old % RING];
+          const auto t_wait = std::chrono::steady_clock::now();
+          for (uint32_t spin = 0; hc[7] != want; spin++) {
+            if ((spin & 0xFFFFu) == 0xFFFFu) {
+              if (hipStreamQuery(main) == hipSuccess && hc[7] != want)
+                return fail(MIRT_E_DEVICE, "queue counters of an iteration never arrived");
+              if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(30))
+                return fail(MIRT_E_DEVICE, "timed out waiting for the queue counters of an iteration");
+            }
+            __builtin_ia32_pause();
+          }
+          std::atomic_thread_fence(std::memory_order_acquire);
+          const uint32_t c_front = hc[0], c_back = hc[1], c_shadow = hc[2], c_culled = hc[4];   // QC_* / CTR_STRIDE
           // a slot that is not finished leaves a ray in one of the queues: empty queues = this half is complete (and
           // every later iteration already launched found them empty too)
-          n_camera += hc[QC_EXT_FRONT];
-          n_bounced += hc[QC_EXT_BACK];
-          n_shadow_rays += hc[QC_SHADOW] - hc[QC_CULLED];
-          const uint32_t in_flight = hc[QC_EXT_FRONT] + hc[QC_EXT_BACK] + hc[QC_SHADOW];
+          n_camera += c_front;
+          n_bounced += c_back;
+          n_shadow_rays += c_shadow - c_culled;
+          const uint32_t in_flight = c_front + c_back + c_shadow;
           if (in_flight == 0) pp.done = true;
-          if (in_flight < pp.a[0].n_slots / 32u) pp.tail = true;
+          if (in_flight < pp.a.n_slots / 32u) pp.tail = true;
         }
       }
     }
@@ -936,9 +964,9 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   HIPCHK(hipEventSynchronize(evB));
   uint32_t err = 0;
   {
-    std::vector<uint32_t> blocks((size_t) 2 * MAX_PIPES * CTRL_WORDS);   // one copy for all the error flags
+    std::vector<uint32_t> blocks((size_t) CTRL_BLOCKS * MAX_PIPES * CTRL_WORDS);   // one copy for all the error flags
     HIPCHK(hipMemcpy(blocks.data(), ctrl, blocks.size() * 4, hipMemcpyDeviceToHost));
-    for (int b = 0; b < 2 * MAX_PIPES; b++) err |= blocks[(size_t) b * CTRL_WORDS + CTRL_ERR];
+    for (int b = 0; b < CTRL_BLOCKS * MAX_PIPES; b++) err |= blocks[(size_t) b * CTRL_WORDS + CTRL_ERR];
   }
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, evA, evB));

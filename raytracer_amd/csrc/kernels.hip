@@ -393,6 +393,8 @@ __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
   const bool listed = !MF && a.live_in != nullptr && (uint64_t) *a.live_in_count * 16u <= (uint64_t) a.n_slots * a.live_16th;
   const uint32_t n = MF ? *a.mf_count : (listed ? *a.live_in_count : a.n_slots);
   const uint32_t K = a.n_lights * a.spl;
+  if (!MF && a.clear_next != nullptr && blockIdx.x == 0)
+    for (uint32_t i = tid; i < a.clear_words; i += 256u) a.clear_next[i] = 0u;
   for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {
     const uint32_t i = base + tid;
     uint32_t s = 0;
@@ -441,6 +443,16 @@ __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
 }
 
 // ============================================================================================ traversal
+// The closest-hit launch of an iteration starts when k_logic has finished, so the queue counters are final: its first wave
+// hands them to the host through host-mapped memory (counters, then - system-scope release - the stamp the host polls).
+// No copy dispatch, no event.
+__device__ __forceinline__ void publish_counters(const TraceArgs &a) {
+  if (a.host_slot == nullptr || blockIdx.x != 0 || threadIdx.x >= 64) return;
+  if (threadIdx.x < (uint32_t) (QC_WORDS / CTR_STRIDE)) a.host_slot[threadIdx.x] = a.qcount[CTR_STRIDE * threadIdx.x];
+  __threadfence_system();
+  if (threadIdx.x == 0) __hip_atomic_store(a.host_slot + 7, a.stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct LaneRay {
   V3 o, d, inv;          // origin, normalised direction (M-T), reciprocal of the ctor argument (slab test)
   float min_t, best_t;
@@ -625,6 +637,7 @@ __device__ __forceinline__ bool slab_exact(const float *lo, const float *hi, con
 
 template<bool ANY>
 __global__ void __launch_bounds__(256) k_trace2(TraceArgs a) {
+  if (!a.redo) publish_counters(a);
   const uint32_t total = a.redo ? *a.redo_count : (a.qcount[a.qc_front] + (a.qc_back >= 0 ? a.qcount[a.qc_back] : 0));
   const uint32_t nA = a.redo ? total : a.qcount[a.qc_front];
   if (a.redo && a.redo_stat && total && blockIdx.x == 0 && threadIdx.x == 0)
@@ -753,6 +766,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
   const uint32_t nthreads = gridDim.x * TRACE_BLOCK;
   const uint32_t nA = a.qcount[a.qc_front];
   const uint32_t total = nA + (a.qc_back >= 0 ? a.qcount[a.qc_back] : 0);
+  publish_counters(a);
 
   LaneRay r;
   r.id = 0; r.best_idx = -1; r.best_t = 0; r.min_t = 0; r.b1 = r.b2 = 0;
@@ -977,6 +991,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
   const uint32_t nthreads = gridDim.x * TRACE_BLOCK;
   const uint32_t nA = a.qcount[a.qc_front];
   const uint32_t total = nA + (a.qc_back >= 0 ? a.qcount[a.qc_back] : 0);
+  publish_counters(a);
 
   LaneRay r;
   r.id = 0; r.best_idx = -1; r.best_t = 0; r.min_t = 0; r.b1 = r.b2 = 0;

@@ -57,6 +57,9 @@ struct RenderArgs {
   uint32_t live_16th;                     // the list is used when it holds at most live_16th / 16 of the slots
   uint32_t cull_zero;                     // mirt_options.flags bit 4: shadow rays whose contribution is exactly 0 are not traced
   const float *lights;                    // 17 dwords per light (mirt_light)
+  // Housekeeping folded into k_logic so that an iteration costs no extra dispatches (host loop):
+  uint32_t *clear_next;                   // k_logic<false>: workgroup 0 zeroes the control block of the NEXT iteration (three
+  uint32_t clear_words;                   //   blocks rotate, so that block is idle now), clear_words words of it
 };
 
 struct TraceArgs {
@@ -87,6 +90,8 @@ struct TraceArgs {
   unsigned long long *count_stat;         // [0] node visits, [1] triangle tests (counting launches only)
   uint32_t count;
   uint32_t require_unit;                  // traversal 0: rays whose ctor direction is not unit length go to k_trace2
+  uint32_t *host_slot;                    // non-null (closest-hit launch of a render iteration): the first wave copies the queue
+  uint32_t stamp;                         //   counters + `stamp` into this host-mapped ring slot (publish_counters)
 };
 
 hipError_t launch_init(const RenderArgs &a, hipStream_t st);
