@@ -1,6 +1,7 @@
 // Command-line renderer written against the reference's host API (the call sequence of the reference's apps/app.cu:24-30:
 // ctor -> set_camera -> resize -> set_scene -> raytrace -> save_to_file), running on libmirt.so.
 //   render out.bmp [--obj file.obj] [--w 640 --h 360 --spp 16 --depth 8] [--rng 0|1] [--device-build]
+//              [--gpus N | --parts N] [--partition spp|tile]     (N GPUs, or N logical partitions of GPU 0; one RCCL reduce)
 // Without --obj it builds the reference's Generator::room plus a few triangles, so it runs with no assets.
 #include <cstdlib>
 #include <cstring>
@@ -10,7 +11,8 @@
 
 int main(int argc, char **argv) {
   std::string out = "out.bmp", obj;
-  uint w = 640, h = 360, spp = 16, depth = 8, rng = 0, device_build = 0;
+  uint w = 640, h = 360, spp = 16, depth = 8, rng = 0, device_build = 0, gpus = 1, parts = 1;
+  std::string partition = "spp";
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     auto next = [&]() { return i + 1 < argc ? argv[++i] : (char *) "0"; };
@@ -21,6 +23,9 @@ int main(int argc, char **argv) {
     else if (a == "--depth") depth = (uint) atoi(next());
     else if (a == "--rng") rng = (uint) atoi(next());
     else if (a == "--device-build") device_build = 2;
+    else if (a == "--gpus") gpus = (uint) atoi(next());
+    else if (a == "--parts") parts = (uint) atoi(next());
+    else if (a == "--partition") partition = next();
     else out = a;
   }
   std::vector<Primitive *> prims;
@@ -39,6 +44,9 @@ int main(int argc, char **argv) {
   PathTracer tracer({spp, 1, spp + 1, 0.05f, depth, 4});
   tracer.options.rng_mode = rng;
   tracer.build_options.own_tree_builder = device_build;
+  for (uint k = 0; k < gpus && gpus > 1; k++) tracer.devices.push_back((int) k);
+  for (uint k = 0; k < parts && parts > 1; k++) tracer.devices.push_back(0);
+  tracer.partition = partition == "tile" ? MIRT_PARTITION_TILE : MIRT_PARTITION_SPP;
   tracer.set_camera({0, 1.5f, -1.95f}, {0, 1.2f, 0}, {0, 1, 0}, 70, 70.f * h / w, 0, INFINITY);
   tracer.resize(w, h);
   tracer.set_scene(prims, lights);

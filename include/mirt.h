@@ -10,7 +10,9 @@
  *   - every function returns 0 on success or a negative MIRT_E_* code; mirt_last_error() gives the message
  *     (the reference prints and returns / exit(1)s: renderer.cuh:118-133, util/misc.cuh:33-43);
  *   - host pointers are caller-owned and only touched during the call; device memory lives behind mirt_scene;
- *   - one render in flight per process (the reference is single-threaded and blocking too, renderer.cuh:178).
+ *   - the library context (streams, events, pinned memory) belongs to the host thread that called mirt_init; one render in
+ *     flight per host thread (the reference is single-threaded and blocking too, renderer.cuh:178); a scene is used from
+ *     the thread that created it.
  *   - the GPU is mandatory: there is no CPU fallback; without a usable HIP device every compute entry point fails with
  *     MIRT_E_DEVICE.
  */
@@ -229,6 +231,29 @@ int mirt_trace(mirt_scene *scene, const float *rays, uint32_t n, int any_hit, ui
 #define MIRT_TRACE_STATIC_MAX_RAYS 65536u
 int mirt_trace_static(mirt_scene *scene, const float *rays_dev, uint32_t n, int any_hit, uint32_t traversal, int32_t *idx_dev,
                       uint32_t *tbits_dev);
+
+/* ---- several GPUs from one host process.  NO COUNTERPART IN THE REFERENCE, which is single-device; this is how
+ * a caller of the kept host API (PathTracer::raytrace, renderer.cuh:117-189) splits a frame over the GPUs of a node without
+ * Python.  A group owns one persistent host thread per member, each with its own library context (the context of
+ * mirt_init is per host thread) and its own replica of the scene.  mirt_group_render: every member renders its partition
+ * of the frame - MIRT_PARTITION_SPP: member r takes samples [r * S / n, (r + 1) * S / n) of every pixel (counter RNG is
+ * switched on; needs S >= n); MIRT_PARTITION_TILE: interleaved 8x8 tiles, bit-identical to one GPU - then ONE sum of the
+ * float4 accumulation buffers onto member 0 (RCCL ncclReduce over xGMI when every member has a GPU of its own - librccl is
+ * loaded at run time, only then; members sharing a GPU are added by a kernel, in member order) and the film as mirt_render
+ * returns it.  devices[]: HIP device index per member; an index may repeat (logical partitions of one GPU).  stats: ray
+ * counts summed over the members, times = the slowest member's.  opts: as mirt_render, tile_* / sample_* must be zero. */
+typedef struct mirt_group mirt_group;
+#define MIRT_PARTITION_SPP 0
+#define MIRT_PARTITION_TILE 1
+int mirt_group_create(const int *devices, int n, mirt_group **out);
+void mirt_group_destroy(mirt_group *group);
+int mirt_group_size(const mirt_group *group);
+/* the scene of mirt_scene_create_opts, replicated on every member (replaces the group's previous scene) */
+int mirt_group_set_scene(mirt_group *group, const float *tri_pos, const float *tri_nrm, const uint32_t *tri_mat,
+                         const uint8_t *prim_type, uint32_t n_prims, const mirt_bsdf *mats, uint32_t n_mats,
+                         const mirt_light *lights, uint32_t n_lights, uint32_t leaf_size, const mirt_build_options *build);
+int mirt_group_render(mirt_group *group, const mirt_camera *camera, const mirt_params *params, const mirt_options *opts,
+                      int partition, uint32_t width, uint32_t height, int32_t *rgb_out, mirt_stats *stats);
 
 /* Replaces PathTracer::save_to_file (renderer.cuh:103-113) + bitmap_image::save_image (util/bitmap_image.cuh:385-430):
  * 24-bit BMP, bottom-up rows padded to 4 bytes. */

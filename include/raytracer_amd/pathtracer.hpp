@@ -287,6 +287,10 @@ public:
   mirt_build_options build_options{};                        // extension: zero = host builders only (own_tree_builder = 1:
                                                              // the traversal's own tree is built on the GPU, for frame loops)
   mirt_stats stats;
+  // extension: more than one entry = the frame is split over these HIP devices (an index may repeat: logical partitions of
+  // one GPU) by sample slices (MIRT_PARTITION_SPP) or interleaved tiles, and summed with one RCCL reduce (mirt_group_*)
+  std::vector<int> devices;
+  int partition = MIRT_PARTITION_SPP;
 
   explicit PathTracer(Parameters p = default_parameters, int device = 0) : parameters(p), camera(nullptr) {
     sample_buffer = std::make_shared<SampleBuffer>();
@@ -294,7 +298,7 @@ public:
     std::memset(&stats, 0, sizeof stats);
     if (mirt_init(device) != MIRT_OK) std::printf("%s\n", mirt_last_error());
   }
-  ~PathTracer() { mirt_scene_destroy(scene_); }
+  ~PathTracer() { mirt_scene_destroy(scene_); mirt_group_destroy(group_); }
   PathTracer(const PathTracer &) = delete;
   PathTracer &operator=(const PathTracer &) = delete;
 
@@ -305,6 +309,7 @@ public:
     lights = l;
     mirt_scene_destroy(scene_);                              // the cached device BVH is dropped, as d_bvh_opt is
     scene_ = nullptr;
+    group_scene_ = false;
   }
 
   void set_camera(const Vector3f &from, const Vector3f &at, const Vector3f &up, float hFov, float vFov, float nClip,
@@ -320,13 +325,27 @@ public:
     if (lights.empty()) { std::printf("LIGHTS NOT SET!"); return; }
     if (sample_buffer->w == 0 || sample_buffer->h == 0) { std::printf("SAMPLE BUFFER EMPTY"); return; }
     std::printf("Starting raytracing...\n");
-    if (!scene_ && !upload()) return;
+    const bool grouped = devices.size() > 1;
+    if (grouped && (!group_ || group_devices_ != devices)) {
+      mirt_group_destroy(group_);
+      group_ = nullptr;
+      group_scene_ = false;
+      if (mirt_group_create(devices.data(), (int) devices.size(), &group_) != MIRT_OK) {
+        std::printf("%s\n", mirt_last_error());
+        return;
+      }
+      group_devices_ = devices;
+    }
+    if ((grouped ? !group_scene_ : !scene_) && !upload(grouped)) return;
     mirt_params prm = {parameters.samples_per_pixel, parameters.samples_per_light, parameters.samples_per_batch,
                        parameters.max_tolerance, parameters.max_ray_depth, parameters.bvh_node_size};
     std::printf("Raytracing Pixels\n");
     static_assert(sizeof(Vector3i) == 12, "film layout");
-    if (mirt_render(scene_, &camera->rec, &prm, &options, sample_buffer->w, sample_buffer->h,
-                    (int32_t *) sample_buffer->data, &stats) != MIRT_OK) {
+    const int rc = grouped ? mirt_group_render(group_, &camera->rec, &prm, &options, partition, sample_buffer->w, sample_buffer->h,
+                                               (int32_t *) sample_buffer->data, &stats)
+                           : mirt_render(scene_, &camera->rec, &prm, &options, sample_buffer->w, sample_buffer->h,
+                                         (int32_t *) sample_buffer->data, &stats);
+    if (rc != MIRT_OK) {
       std::fprintf(stderr, "Fatal error: %s\n*** FAILED - ABORTING\n", mirt_last_error());   // util/misc.cuh:33-43
       std::exit(1);
     }
@@ -342,8 +361,11 @@ public:
 
 private:
   mirt_scene *scene_ = nullptr;
+  mirt_group *group_ = nullptr;
+  std::vector<int> group_devices_;
+  bool group_scene_ = false;
 
-  bool upload() {
+  bool upload(bool grouped = false) {
     std::printf("Creating BVH\n");
     std::vector<float> pos, nrm;
     std::vector<uint32_t> mat;
@@ -375,6 +397,17 @@ private:
     }
     std::vector<mirt_light> ls;
     for (const SceneLight &l: lights) ls.push_back(l.rec);
+    if (grouped) {
+      if (mirt_group_set_scene(group_, pos.data(), nrm.data(), mat.data(), ptype.data(), (uint32_t) mat.size(), mats.data(),
+                               (uint32_t) mats.size(), ls.data(), (uint32_t) ls.size(), parameters.bvh_node_size,
+                               &build_options) != MIRT_OK) {
+        std::printf("%s\n", mirt_last_error());
+        return false;
+      }
+      group_scene_ = true;
+      std::printf("Created BVH\nOptimized BVH\nMoved BVH to %d GPU contexts\n", mirt_group_size(group_));
+      return true;
+    }
     if (mirt_scene_create_opts(pos.data(), nrm.data(), mat.data(), ptype.data(), (uint32_t) mat.size(), mats.data(),
                                (uint32_t) mats.size(), ls.data(), (uint32_t) ls.size(), parameters.bvh_node_size,
                                &build_options, &scene_) != MIRT_OK) {

@@ -15,7 +15,8 @@ SYMBOLS = [
     "mirt_scene_create_opts", "mirt_scene_destroy", "mirt_scene_build_times", "mirt_scene_own_tree",
     "mirt_scene_info", "mirt_scene_bvh2", "mirt_camera_look_at", "mirt_render", "mirt_render_accum", "mirt_tonemap",
     "mirt_primary_hits", "mirt_trace", "mirt_save_bmp", "mirt_tonemap_host", "mirt_bvh_build_host",
-    "mirt_bvh_build_host_prims", "mirt_trace_static",
+    "mirt_bvh_build_host_prims", "mirt_trace_static", "mirt_group_create", "mirt_group_destroy", "mirt_group_size",
+    "mirt_group_set_scene", "mirt_group_render",
 ]
 
 
@@ -85,6 +86,7 @@ def load():
         lib.mirt_last_error.restype = C.c_char_p
         lib.mirt_version.restype = C.c_char_p
         lib.mirt_scene_destroy.restype = None
+        lib.mirt_group_destroy.restype = None
         lib.mirt_shutdown.restype = None
         _lib = lib
     return _lib
@@ -284,6 +286,51 @@ class Scene:
         _chk(load().mirt_trace(self.h, _p(rays8), C.c_uint32(n), C.c_int(int(anyhit)), C.c_uint32(traversal), _p(idx),
                                _p(tb), _p(b)))
         return (idx, tb, b) if bary else (idx, tb)
+
+
+class Group:
+    """mirt_group_*: one frame over several GPUs (or logical partitions of one) from this process."""
+
+    def __init__(self, devices):
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _chk(load().mirt_group_create(arr, C.c_int(len(devices)), C.byref(h)))
+        self.h = h
+        self.camera = CameraRec()
+
+    def close(self):
+        if getattr(self, "h", None):
+            load().mirt_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, sc, leaf_size=4):
+        mats, lights = bsdf_records(sc.mats), light_records(sc.lights)
+        _chk(load().mirt_group_set_scene(self.h, _p(sc.pos), _p(sc.nrm), _p(sc.mat), _p(getattr(sc, "ptype", None)), C.c_uint32(sc.n),
+                                         _p(mats), C.c_uint32(len(mats)), _p(lights) if len(lights) else None,
+                                         C.c_uint32(len(lights)), C.c_uint32(leaf_size), None))
+        rec = CameraRec()
+        cam = sc.camera
+        v = lambda t: (C.c_float * 3)(*t)
+        _chk(load().mirt_camera_look_at(v(cam.look_from), v(cam.look_at), v(cam.up), C.c_float(cam.hfov), C.c_float(cam.vfov),
+                                        C.c_float(cam.nclip), C.c_float(cam.fclip), C.c_float(cam.aperture), C.c_float(cam.focal),
+                                        C.byref(rec)))
+        self.camera = rec
+
+    def render(self, w, h, partition="spp", spp=4, spl=1, batch=64, tol=0.05, depth=4, leaf=4, **opt):
+        prm = Params(spp, spl, batch, tol, depth, leaf)
+        o = Scene.options(**opt)
+        st = Stats()
+        rgb = np.zeros((h, w, 3), np.int32)
+        _chk(load().mirt_group_render(self.h, C.byref(self.camera), C.byref(prm), C.byref(o), C.c_int(1 if partition == "tile" else 0),
+                                      C.c_uint32(w), C.c_uint32(h), _p(rgb), C.byref(st)))
+        self.last = st.as_dict()
+        return rgb
 
 
 TRACE_STATIC_MAX_RAYS = 65536

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -101,7 +102,10 @@ struct Global {
     }
     return pool[pool_used++];
   }
-} G;
+};
+// One context per host thread: a process that drives several GPUs (mirt_group_*, group.hip) runs one thread per device, each
+// with its own streams, events and pinned memory; a single-threaded caller sees exactly one context, as before.
+thread_local Global G;
 
 struct Timed { int kind; hipEvent_t a, b; };   // kind 0 logic, 1 closest trace, 2 shadow trace
 
@@ -139,10 +143,16 @@ constexpr size_t SO_OVF = SO_REDO + (size_t) STATIC_MAX_RAYS * 4;
 constexpr size_t SCRATCH_BYTES = SO_OVF + (size_t) STATIC_OVF_DEPTH * STATIC_GRID * TRACE_BLOCK * sizeof(uint2);   // ~ 23 MB
 constexpr int MAX_DEVICES = 64;
 unsigned char *g_scratch_ptr[MAX_DEVICES] = {};                          // per device: its copy's address
+std::mutex g_scratch_mutex;
 
 }  // namespace
 
 static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
+namespace mirt {
+hipStream_t current_stream() { return G.stream; }                        // for group.hip
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+}  // namespace mirt
 
 struct mirt_scene {
   HostBVH bvh;
@@ -203,10 +213,13 @@ int mirt_init(int device) {
   }
   G.stream = G.pstream[0];
   G.side = G.pside[0];
-  if (device < MAX_DEVICES && !g_scratch_ptr[device]) {
-    void *ptr = nullptr;
-    HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));               // this device's copy (hipSetDevice above)
-    g_scratch_ptr[device] = (unsigned char *) ptr;
+  if (device < MAX_DEVICES) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+      void *ptr = nullptr;
+      HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));             // this device's copy (hipSetDevice above)
+      g_scratch_ptr[device] = (unsigned char *) ptr;
+    }
   }
   G.table_exact = build_tonemap_table(G.table);
   HIPCHK(G.d_table.ensure(sizeof(G.table)));
@@ -1049,10 +1062,12 @@ int mirt_tonemap(const void *accum_dev, uint32_t width, uint32_t height, int32_t
     return fail(MIRT_E_DEVICE, std::string("tonemap: ") + hipGetErrorString(e));
   }
   std::atomic<int> bad{0};
+  const hipEvent_t *film_ev = G.film_ev;                                 // (the context is per thread: the workers get copies)
+  const uint32_t *h_film = G.h_film;
   parallel_for(PIECES, [&](size_t k0, size_t k1) {
     for (size_t k = k0; k < k1; k++) {
-      if (hipEventSynchronize(G.film_ev[k]) != hipSuccess) { bad.store(1); continue; }
-      const uint32_t *src = G.h_film;
+      if (hipEventSynchronize(film_ev[k]) != hipSuccess) { bad.store(1); continue; }
+      const uint32_t *src = h_film;
       for (size_t i = cut[k]; i < cut[k + 1]; i++) {
         const uint32_t v = src[i];
         rgb_out[3 * i] = (int32_t) (v & 0xFFu);
