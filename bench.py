@@ -84,30 +84,38 @@ def traffic_per_launch(args, world):
 
 
 def cpu_baseline(scene_data, args):
-    """Reference CPU path on a bounded sample of the same workload: half-resolution frame (a quarter of the pixels), same
-    spp and depth: ~10-20 s of work for 16 threads."""
+    """The reference's CPU path on bounded samples of the same workload: all threads of the box's CPU share
+    on a half-resolution frame (a quarter of the pixels, same spp and depth: ~10-20 s), and ONE thread on a 1/64 sample
+    (quarter resolution, a quarter of the spp: a few seconds).  `kind` "reference" = oracle/_ref/libref.so, the reference's own
+    headers compiled in the build container (the source never travels; the prebuilt library does); "port" = the C oracle,
+    when that library is absent.  Rays are counted by the C oracle, whose control flow is bit-identical."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cpulibs import CpuTracer, ref_available
 
-    threads = args.cpu_threads or min(16, os.cpu_count() or 1)
-    w, h, spp = args.width // 2, args.height // 2, args.spp
+    nproc = os.cpu_count() or 1
+    threads = args.cpu_threads or min(16, nproc)          # the box's CPU share for one GPU is 16 cores; nproc shows the whole machine
     cam = scene_data.camera
-    kw = dict(spp=spp, spl=1, batch=spp + 1, tol=0.0, depth=args.depth, nthreads=threads)
-    orc = CpuTracer("oracle").load(scene_data)
-    orc.set_camera(cam)
-    orc.render(w, h, **kw)
-    rays = orc.last["closest"] + orc.last["shadow"]
-    kind, secs = "port", orc.last["seconds"]
-    if ref_available():
-        ref = CpuTracer("ref").load(scene_data)
-        ref.set_camera(cam)
-        ref.render(w, h, **kw)
-        kind, secs = "reference", ref.last["seconds"]
-        ref.close()
-    orc.close()
-    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": threads, "kind": kind,
-            "sample": f"{scene_data.name} {w}x{h}, {spp} spp, depth {args.depth}, {rays} rays in {secs:.2f} s "
-                      f"(rays counted by the C oracle, whose control flow is bit-identical)"}
+    kind = "reference" if ref_available() else "port"
+
+    def run(w, h, spp, nthreads):
+        kw = dict(spp=spp, spl=1, batch=spp + 1, tol=0.0, depth=args.depth, nthreads=nthreads)
+        orc = CpuTracer("oracle").load(scene_data)
+        orc.set_camera(cam)
+        orc.render(w, h, **kw)
+        rays, secs = orc.last["closest"] + orc.last["shadow"], orc.last["seconds"]
+        orc.close()
+        if kind == "reference":
+            ref = CpuTracer("ref").load(scene_data)
+            ref.set_camera(cam)
+            ref.render(w, h, **kw)
+            secs = ref.last["seconds"]
+            ref.close()
+        return rays / secs / 1e6, f"{scene_data.name} {w}x{h}, {spp} spp, depth {args.depth}, {rays} rays in {secs:.2f} s"
+
+    many, many_sample = run(args.width // 2, args.height // 2, args.spp, threads)
+    one, one_sample = run(max(8, args.width // 4), max(8, args.height // 4), max(1, args.spp // 4), 1)
+    return {"value": many, "unit": "Mrays/s", "cores": threads, "kind": kind, "sample": many_sample, "nproc": nproc,
+            "single_thread": {"value": one, "unit": "Mrays/s", "cores": 1, "sample": one_sample}}
 
 
 def main():
@@ -136,7 +144,7 @@ def main():
     from raytracer_amd import capi, scenes
 
     capi.init(local_rank)
-    sd = scenes.WORKLOADS[args.workload]()
+    sd, data_kind = scenes.workload(args.workload)             # objects/<name>.obj when present, else the stand-in of SURVEY 8(d)
     sd.camera = sd.camera.for_aspect(args.width, args.height)
     t0 = time.time()
     scene = capi.Scene(sd, builder=args.builder)
@@ -220,7 +228,8 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (procedural stand-in scene: the reference's .obj meshes are absent)",
+            "data": "real (objects/%s.obj)" % args.workload.rstrip("*") if data_kind == "real"
+                    else "synthetic (procedural stand-in scene: the reference's .obj meshes are absent)",
             "config": {"workload": f"{args.workload} {sd.n} tris, {w}x{h}, {args.spp} spp, depth {args.depth}, "
                                    f"{len(sd.lights)} light{'s' if len(sd.lights) != 1 else ''}, rng {'counter' if opt['rng_mode'] else 'xorshift'}, "
                                    f"traversal {args.traversal}, {opt['streams']} sample streams",

@@ -31,6 +31,12 @@ struct Vector3f {
   Vector3f operator-(const Vector3f &v) const { return {x - v.x, y - v.y, z - v.z}; }
   Vector3f operator-() const { return {-x, -y, -z}; }
   void operator+=(const Vector3f &v) { x += v.x; y += v.y; z += v.z; }
+  Vector3f operator*(float c) const { return {x * c, y * c, z * c}; }
+  Vector3f operator/(float c) const {                       // linalg/Vector3f.cuh:106-109: reciprocal in double, three multiplies
+    float rc = (float) (1.0 / (double) c);
+    return {x * rc, y * rc, z * rc};
+  }
+  Vector3f cross(const Vector3f &v) const { return {y * v.z - z * v.y, z * v.x - x * v.z, x * v.y - y * v.x}; }
   float norm() const { return (float) std::sqrt((double) (x * x + y * y + z * z)); }
   Vector3f unit() const {                                   // linalg/Vector3f.cuh:161-164
     float r = (float) (1. / (double) norm());

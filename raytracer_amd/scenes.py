@@ -3,7 +3,8 @@
 The four meshes BASELINE.json names (bunny / buddha / conference / sportsCar .obj) are absent from the
 reference mount (``/root/reference/.MISSING_LARGE_BLOBS``), so the bench and the tests use the
 deterministic procedural stand-ins SURVEY.md 8(d) defines.  If the real ``.obj`` files are dropped into
-``objects/``, :func:`load_obj_scene` reads them instead (own parser, raytracer_amd/objio.py).
+``objects/``, :func:`load_obj_scene` reads them instead (through the C++ host mirror's ``Generator::from_obj``, i.e. the
+parser a caller of the kept host API gets: include/raytracer_amd/pathtracer.hpp, dumped by raytracer_amd/obj_info).
 
 Array conventions (identical for the HIP path, the C oracle and the reference harness):
   pos    (N, 9) f32   p1 p2 p3 per triangle            (reference: primitives.cuh:23-26)
@@ -429,6 +430,52 @@ def sphere_soup(n_tri=300, n_sph=60, seed=3):
     perm = rng.permutation(n_tri + n_sph)
     return SceneData(f"sphere_soup{n_tri}_{n_sph}", pos[perm], nrm[perm], mat[perm], t.mats, t.lights, t.camera,
                      ptype=ptype[perm]).finalize()
+
+
+def load_obj_scene(path, name=None, default_bsdf=None, scale=(1, 1, 1), translate=(0, 0, 0)):
+    """A real OBJ/MTL pair as a SceneData, read by the C++ host mirror's Generator::from_obj (reference:
+    geometry/generator.cuh:98-180; rapidobj parity unpinned).  The reference records no camera or lights for
+    its meshes (from_obj has no caller there): the camera is fitted to the bounding box (three quarters view from
+    outside), lights = the directional light of SURVEY 8(d) + an area light above the mesh."""
+    import subprocess
+    import tempfile
+
+    tool = os.path.join(_ROOT, "raytracer_amd", "obj_info")
+    if not os.path.exists(tool):
+        raise FileNotFoundError(f"{tool} is missing: run `make -C raytracer_amd/csrc all`")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "mesh.bin")
+        args = [tool, "--bin", out, path] + [repr(float(v)) for v in (*scale, *translate)]
+        r = subprocess.run(args, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"obj_info failed on {path}: {r.stdout}{r.stderr}")
+        raw = np.fromfile(out, np.uint32)
+    n = int(raw[0])
+    tri = raw[1:1 + 18 * n].view(np.float32).reshape(n, 18)
+    rec = raw[1 + 18 * n:1 + 27 * n].reshape(n, 9)
+    uniq, mat = np.unique(rec, axis=0, return_inverse=True)         # one material per distinct BSDF record
+    mats = np.concatenate([uniq[:, :1].astype(np.float32), uniq[:, 1:].view(np.float32)], axis=1)
+    if default_bsdf is not None:
+        mats, mat = np.array([default_bsdf], np.float32), np.zeros(n, np.uint32)
+    pts = tri[:, :9].reshape(-1, 3)
+    lo, hi = pts.min(0).astype(np.float64), pts.max(0).astype(np.float64)
+    c, ext = (lo + hi) / 2, float(np.linalg.norm(hi - lo))
+    cam = Camera(tuple(c + ext * np.array([0.45, 0.35, -0.95])), tuple(c), hfov=42, vfov=42 * 9 / 16)
+    top = hi[1] + 0.05 * ext
+    lights = np.array([directional_light((.5, .5, .5), (-1, -1, 1)),
+                       area_light((12, 12, 12), (c[0], top, c[2]), (0, -1, 0), (0.3 * ext, 0, 0), (0, 0, 0.3 * ext))])
+    return SceneData(name or os.path.basename(path), tri[:, :9].copy(), tri[:, 9:].copy(), mat.astype(np.uint32), mats, lights,
+                     cam).finalize()
+
+
+def workload(name):
+    """(SceneData, "real" | "synthetic"): `objects/<name>.obj` when somebody has dropped the real mesh there (the reference
+    mount lacks the four meshes: .MISSING_LARGE_BLOBS), else the procedural stand-in of SURVEY 8(d)."""
+    base = name.rstrip("*")
+    path = os.path.join(_ROOT, "objects", base + ".obj")
+    if os.path.exists(path):
+        return load_obj_scene(path, base, default_bsdf=WHITE if base in ("bunny", "buddha") else None), "real"
+    return WORKLOADS[name if name in WORKLOADS else base + "*"](), "synthetic"
 
 
 WORKLOADS = {

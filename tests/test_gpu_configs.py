@@ -283,3 +283,41 @@ def test_one_hundred_thousand_spheres(mirt, oracle):
     ref = oracle.render(320, 180, spp=2, depth=4, batch=3, tol=0.0, nthreads=8)
     assert (img == ref).mean() >= 0.999
     s.close()
+
+
+def test_far_small_spheres_the_reference_apps_regime(mirt, oracle):
+    """apps/app.cu: spheres of radius 0.2 seen from ~350 units, lit by the axis-parallel directional light (0,-1,0).  Two things
+    only this regime shows: (1) the reference's sphere test cancels catastrophically at that distance, so the hit it works
+    with can sit beside the sphere's own bounding box - the ordered traversal dilates its boxes for sphere scenes (before it
+    did, 2-4 of 30 000 primary hits differed); (2) every shadow ray has two zero direction components and takes the
+    reference walk (one ray per lane when there are that many)."""
+    rng = np.random.default_rng(5)
+    n = 20000
+    pos = np.zeros((n + 2, 9), np.float32)
+    d = rng.normal(size=(n, 3))
+    d[:, 1] = np.abs(d[:, 1])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pos[:n, :3] = d * rng.uniform(0, 18, (n, 1))
+    pos[:n, 3] = 0.2
+    pos[n] = [-5000, 0, -5000, 5000, 0, -5000, 5000, 0, 5000]
+    pos[n + 1] = [-5000, 0, -5000, -5000, 0, 5000, 5000, 0, 5000]
+    nrm = np.zeros((n + 2, 9), np.float32)
+    nrm[n:] = [0, 1, 0] * 3
+    mats = np.concatenate([[scenes.WHITE], [scenes.emission(*rng.uniform(0.2, 1, 3)) for _ in range(n)]])
+    mat = np.concatenate([np.arange(1, n + 1), [0, 0]]).astype(np.uint32)
+    sc = scenes.SceneData("particles", pos, nrm, mat, mats, np.array([scenes.directional_light((.2, .2, .2), (0, -1, 0))]),
+                          scenes.Camera((0, 175, -300), (0, 20, 0), hfov=42, vfov=31),
+                          ptype=np.concatenate([np.full(n, 1, np.uint8), np.full(2, 2, np.uint8)])).finalize()
+    oracle.load(sc)
+    w, h = 200, 150
+    oi, ot = oracle.primary_hits(w, h)
+    ref = oracle.render(w, h, spp=8, depth=8, batch=64, tol=0.05, nthreads=8)
+    for builder in ("host", "device", "ploc"):
+        s = mirt.Scene(sc, builder=builder)
+        gi, gt = s.primary_hits(w, h, traversal=0)
+        assert (gi == oi).all() and (gt == ot).all(), f"{builder}: {(gi != oi).sum()} primary hits differ"
+        img = s.render(w, h, spp=8, depth=8, batch=64, tol=0.05)
+        assert (img == ref).mean() >= 0.999
+        assert s.last["exact_fallback_rays"] >= s.last["shadow_rays"] > 100000        # every shadow ray took the reference walk
+        s.close()
+    assert len(np.unique(oi)) > 300

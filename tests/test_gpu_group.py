@@ -81,3 +81,21 @@ def test_rccl_binding_single_member(tmp_path):
     env = dict(os.environ, MIRT_GROUP_FORCE_RCCL="1")
     r = subprocess.run(["python3", "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_particle_app_frame_loop(tmp_path):
+    """apps/app.cpp = the reference's apps/app.cu (particle physics -> spheres + floor -> PathTracer -> BMP per frame) on a
+    reduced configuration: the films do not depend on who builds the traversal's own tree (GPU PLOC by default, host SAH),
+    frames differ (the particles move) and are lit."""
+    app = os.path.join(ROOT, "raytracer_amd", "particle_app")
+    assert os.path.exists(app), "build it with make -C raytracer_amd/csrc all"
+    sets = []
+    for extra in ([], ["--host-build"]):
+        prefix = str(tmp_path / f"b{len(sets)}_")
+        r = subprocess.run([app, "--frames", "3", "--particles", "30000", "--w", "200", "--h", "150", "--spp", "8", "--prefix", prefix]
+                           + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "frames/s" in r.stdout, r.stdout + r.stderr
+        sets.append([open(prefix + f"{i}.bmp", "rb").read() for i in range(3)])
+    assert sets[0] == sets[1]
+    a, b = (np.frombuffer(x, np.uint8)[54:].astype(int) for x in sets[0][:2])
+    assert (a != b).mean() > 0.01 and a.mean() > 2

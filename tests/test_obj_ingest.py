@@ -109,3 +109,30 @@ def test_from_obj_defaults_and_errors(tmp_path):
     assert np.allclose(bsdf[0][1:4], 0.6) and np.array_equal(tris[0, 9:12], np.array([0, 0, 1], np.float32))
     r = subprocess.run([TOOL, str(tmp_path / "missing.obj")], capture_output=True, text=True)
     assert r.returncode == 1 and "could not open" in r.stdout
+
+
+def test_load_obj_scene_through_the_host_mirror(tmp_path):
+    """scenes.load_obj_scene / scenes.workload: what bench.py uses when a real mesh sits in objects/ (binary dump of the C++
+    Generator::from_obj): triangles, normals and the MTL -> BSDF materials arrive as the text dump has them."""
+    import shutil
+
+    shutil.copy(os.path.join(ROOT, "objects", "sportsCar.mtl"), tmp_path / "sportsCar.mtl")
+    names = [m["name"] for m in scenes.parse_mtl(os.path.join(ROOT, "objects", "sportsCar.mtl"))]
+    rng = np.random.default_rng(3)
+    V = rng.uniform(-1, 1, (40, 3))
+    lines = ["mtllib sportsCar.mtl"] + [f"v {x:.6f} {y:.6f} {z:.6f}" for x, y, z in V] + ["vn 0 1 0"]
+    for k, nm in enumerate(names):
+        a, b, c = rng.choice(40, 3, replace=False) + 1
+        lines += [f"usemtl {nm}", f"f {a}//1 {b}//1 {c}//1"]
+    path = tmp_path / "car.obj"
+    path.write_text("\n".join(lines) + "\n")
+    sc = scenes.load_obj_scene(str(path))
+    assert sc.n == len(names) and sc.pos.shape == (sc.n, 9)
+    want = np.array([scenes.mtl_to_bsdf(m) for m in scenes.parse_mtl(os.path.join(ROOT, "objects", "sportsCar.mtl"))], np.float32)
+    assert np.allclose(sc.mats[sc.mat], want, rtol=0, atol=0)               # per triangle: the material the MTL rule gives
+    assert (sc.nrm.reshape(-1, 3) == [0, 1, 0]).all() and len(sc.lights) == 2
+    txt = subprocess.run([TOOL, str(path)], capture_output=True, text=True).stdout
+    rows = np.array([[float(v) for v in ln.split()] for ln in txt.strip().split("\n")], np.float32)
+    assert (rows[:, :9] == sc.pos).all()
+    sd, kind = scenes.workload("conference*")
+    assert kind == "synthetic" and sd.n > 300000                           # the reference mount lacks the meshes
