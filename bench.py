@@ -56,7 +56,6 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (what the driver runs); gloo = rehearsal of the N > 1 path on a box "
                          "with fewer GPUs than ranks: ranks share the GPUs and the buffers are summed through host memory")
-    ap.add_argument("--split", action="store_true", help="add the per-kernel time split of one extra frame to the roofline object")
     ap.add_argument("--builder", default=None, choices=["host", "device", "ploc"],
                     help="who builds the ordered traversal's own tree (default: the library's, host binned SAH)")
     ap.add_argument("--cull-zero", action="store_true",
@@ -67,20 +66,20 @@ def parse():
     return ap.parse_args()
 
 
-def traffic_per_launch(args, world):
-    """HBM bytes per launch of the dominant kernel, from the committed PMC passes of this same command (rocprofv3 cannot
-    wrap itself: tools/make_profiles.sh collects FETCH_SIZE / WRITE_SIZE in separate runs, profiles/traffic.json holds the
-    corrected figure).  None when the file is absent or was collected on another configuration than the one running."""
+def traffic_table(args, world):
+    """HBM bytes per launch of the three hot kernels, from the committed PMC passes of this same command (rocprofv3 cannot
+    wrap itself: tools/make_profiles.sh collects FETCH_SIZE / WRITE_SIZE in separate runs and writes profiles/traffic.json
+    with the corrected figures).  {} when the file is absent or was collected on another configuration than the one running."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             d = json.load(fh)
         mine = {"workload": args.workload, "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth,
                 "streams": args.streams, "traversal": args.traversal, "n_gpus": world}
         if d.get("configuration") != mine:
-            return None
-        return d["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+            return {}
+        return {k: v["hbm_bytes_per_launch"] for k, v in d["kernels"].items()}
+    except (OSError, KeyError, ValueError, TypeError):
+        return {}
 
 
 def cpu_baseline(scene_data, args):
@@ -200,11 +199,10 @@ def main():
         # traversal work per ray (counting build of the same kernels, one untimed reduced-spp frame)
         cnt = scene.render_accum(w, h, accum.data_ptr(), spp=min(4, args.spp), spl=1, batch=args.spp + 1, tol=0.0,
                                  depth=args.depth, **{**opt, "count": True, "sample_count": 0, "sample_begin": 0})
-        # optional: one more untimed frame with events around every launch, for the per-kernel split (not by default, so
-        # that a kernel trace of the default command holds the launches of the warm-up and timed frames only)
-        split = None
-        if args.split:
-            split = scene.render_accum(w, h, accum.data_ptr(), **kw, **{**opt, "profile": True, "profile_closest": False})
+        # one more untimed frame with events around EVERY launch: the per-kernel lines of the roofline (the timed steps carry
+        # events around the closest-hit launches only)
+        split = scene.render_accum(w, h, accum.data_ptr(), **kw, **{**opt, "profile": True, "profile_closest": False,
+                                                                  "sample_count": 0, "sample_begin": 0})
         n_node = cnt["closest_node_visits"] / max(1, cnt["closest_rays"])
         n_tri = cnt["closest_tri_tests"] / max(1, cnt["closest_rays"])
         b_ray = B_STATE_CLOSEST + n_node * S_NODE[args.traversal] + n_tri * S_TRI
@@ -213,6 +211,30 @@ def main():
         k_rays = sum(s["closest_rays"] for s in stats)
         avg_launch_ms = k_ms / max(1, launches)
         achieved = (k_rays * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = traffic_table(args, world)
+        tname = "k_trace_fast" if args.traversal == 0 else "k_trace4" if args.traversal == 1 else "k_trace2"
+        # shadow rays: 96 B of state (ray write + read, contribution write + read) + their own traversal counts;
+        # k_logic per slot and iteration: state it reads (7 x 16 B + K x 20 B of shadow results + 48 B of normals + 48 B of
+        # material) and writes (6 x 16 B + K x 48 B of shadow rays + queue and live-list entries)
+        K = len(sd.lights) * 1
+        sn = cnt["shadow_node_visits"] / max(1, cnt["shadow_rays"])
+        st_ = cnt["shadow_tri_tests"] / max(1, cnt["shadow_rays"])
+        b_shadow = 96 + sn * S_NODE[args.traversal] + st_ * S_TRI
+        b_slot = (208 + 20 * K) + (96 + 48 * K) + (8 + 4 * K)
+        slots_per_launch = (w + 7) // 8 * ((h + 7) // 8) * 64 * max(1, opt["streams"]) / max(1, round(split["logic_launches"] / max(1, split["iterations"])))
+
+        def line(name, units, unit_name, b_unit, ms, n_launch):
+            ach = units * b_unit / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            t = traffic.get(name)
+            return {"kernel": name, "launches": n_launch, "avg_launch_ms": ms / max(1, n_launch), f"{unit_name}_per_launch": units / max(1, n_launch),
+                    f"bytes_per_{unit_name}": b_unit, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": t,
+                    "hbm_frac": None if t is None or ms <= 0 else t / (ms * 1e-3 / max(1, n_launch)) / 1e9 / HBM_PEAK_GBS}
+
+        per_kernel = [
+            line(f"{tname}<closest>", split["closest_rays"], "ray", b_ray, split["trace_closest_ms"], split["closest_launches"]),
+            line(f"{tname}<any>", split["shadow_rays"], "ray", b_shadow, split["trace_shadow_ms"], split["shadow_launches"]),
+            line("k_logic", slots_per_launch * split["logic_launches"], "slot", b_slot, split["logic_ms"], split["logic_launches"]),
+        ]
         out = {
             "metric": f"Mrays/s (all bounces), {args.workload.rstrip('*')}.obj stand-in {args.width}x{args.height} {args.spp}spp"
                       if (args.workload, args.width, args.height, args.spp) != ("conference*", 1920, 1080, 64)
@@ -236,14 +258,19 @@ def main():
                        "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
                        "reference_walk_rays_per_frame": sum(s["exact_fallback_rays"] for s in stats) / max(1, args.steps),
                        "scene_build_s": build_s, "builder": args.builder or "host", "build_ms": build_ms},
+            # the dominant kernel (closest-hit traversal) measured inside the timed steps; `kernels`: all three hot kernels in
+            # one extra frame with events around every launch.  `frac` = algorithmic bytes / time / HBM peak (the contract's
+            # figure); `hbm_frac` = measured HBM traffic (PMC) / time / HBM peak: what the kernel really asks of HBM - the
+            # traversal kernels are bound by the vector-L1 / L2 request rate of their divergent gathers, not by HBM
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_per_launch(args, world),
-                         "kernel": "k_trace_fast<closest>" if args.traversal == 0 else "k_trace4<closest>", "avg_launch_ms": avg_launch_ms, "launches": launches,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get(f"{tname}<closest>"),
+                         "kernel": f"{tname}<closest>", "avg_launch_ms": avg_launch_ms, "launches": launches,
                          "bytes_per_ray": b_ray, "node_visits_per_ray": n_node, "tri_tests_per_ray": n_tri,
                          "kernel_rays_per_s": k_rays / (k_ms * 1e-3) if k_ms > 0 else 0.0,
                          "closest_kernel_ms_timed_steps": k_ms,
-                         "one_frame_kernel_ms": None if split is None else {
-                             "closest": split["trace_closest_ms"], "shadow": split["trace_shadow_ms"], "logic": split["logic_ms"]}},
+                         "hbm_frac": None if traffic.get(f"{tname}<closest>") is None or avg_launch_ms <= 0
+                         else traffic[f"{tname}<closest>"] / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "kernels": per_kernel},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, args)

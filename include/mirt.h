@@ -115,7 +115,8 @@ typedef struct mirt_stats {
   uint64_t closest_node_steps, closest_tri_steps, shadow_node_steps, shadow_tri_steps;
   /* the traversal that ran: opts->traversal, except that 0 becomes 1 for a scene whose own tree could not be built
    * (non-finite vertex coordinates) */
-  uint32_t traversal_used, reserved;
+  uint32_t traversal_used;
+  uint32_t logic_launches;  /* launches of k_logic behind logic_ms (flags bit 0) */
 } mirt_stats;
 
 typedef struct mirt_scene mirt_scene;

@@ -1018,6 +1018,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     stats->shadow_node_steps = rs[10];
     stats->shadow_tri_steps = rs[11];
     stats->traversal_used = o.traversal;
+    stats->logic_launches = n_kind[0];
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   }
   return MIRT_OK;

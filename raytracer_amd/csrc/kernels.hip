@@ -548,9 +548,8 @@ __device__ __forceinline__ bool own_box_admits(const V3 lo, const V3 hi, const L
 //     "hit" that Moeller-Trumbore reports from outside the triangle (its barycentrics are ill-conditioned when the ray runs
 //     almost in the triangle's plane).  The reference finds such hits or not depending on its boxes.
 template<bool SPH>
-__device__ __forceinline__ bool tri_test_near(const float4 *tris, const float *verts, uint32_t idx, const LaneRay &r, float max_t,
-                                              float near_rel, float &t, float &by, float &bz, uint32_t &flat, bool &near) {
-  const float4 q0 = tris[3 * (size_t) idx], q1 = tris[3 * (size_t) idx + 1], q2 = tris[3 * (size_t) idx + 2];
+__device__ __forceinline__ bool tri_test_near(const float4 q0, const float4 q1, const float4 q2, const float *verts, const LaneRay &r,
+                                              float max_t, float near_rel, float &t, float &by, float &bz, uint32_t &flat, bool &near) {
   flat = f2u(q2.y);
   if (SPH && f2u(q2.z) != 0u) {
     const SphereHit h = sphere_eval(q0, q1, r);
@@ -1060,21 +1059,32 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
   };
   // (a stack deeper than LDS + overflow region cannot happen for the tree the region was sized for; if it does, the entry
   // lands on the last slot, the ray is flagged and the launch reports it once the ray ends)
+  // Occlusion rays never look at an entry's distance: their entries are 4 bytes, and twice as many fit the lane's LDS part.
+  constexpr int NSTK = ANY ? 2 * LDS_STACK : LDS_STACK;
+  uint32_t *lds_stack32 = (uint32_t *) lds_stack;
   bool too_deep = false;
-  const int sp_max = LDS_STACK + (int) a.ovf_depth - 1;
+  const int sp_max = NSTK + (int) a.ovf_depth - 1;
   auto push = [&](uint32_t ref, float tmn) {
     too_deep = too_deep || sp > sp_max;
     const int at = sp > sp_max ? sp_max : sp;
-    if (at < LDS_STACK) lds_stack[at * TRACE_BLOCK + tid] = make_uint2(ref, f2u(tmn));
-    else a.ovf[(size_t) (at - LDS_STACK) * nthreads + gtid] = make_uint2(ref, f2u(tmn));
+    if (at < NSTK) {
+      if (ANY) lds_stack32[at * TRACE_BLOCK + tid] = ref;
+      else lds_stack[at * TRACE_BLOCK + tid] = make_uint2(ref, f2u(tmn));
+    } else {
+      a.ovf[(size_t) (at - NSTK) * nthreads + gtid] = make_uint2(ref, f2u(tmn));
+    }
     sp = at + 1;
   };
   auto pop = [&]() {
     uint32_t next = CHILD_EMPTY;
     while (sp > 0) {
       sp--;
-      uint2 e = (sp < LDS_STACK) ? lds_stack[sp * TRACE_BLOCK + tid] : a.ovf[(size_t) (sp - LDS_STACK) * nthreads + gtid];
-      if (ANY || u2f(e.y) <= r.best_t * SLACK) { next = e.x; break; }
+      if (ANY) {
+        next = (sp < NSTK) ? lds_stack32[sp * TRACE_BLOCK + tid] : a.ovf[(size_t) (sp - NSTK) * nthreads + gtid].x;
+        break;
+      }
+      uint2 e = (sp < NSTK) ? lds_stack[sp * TRACE_BLOCK + tid] : a.ovf[(size_t) (sp - NSTK) * nthreads + gtid];
+      if (u2f(e.y) <= r.best_t * SLACK) { next = e.x; break; }
     }
     enter(next);
   };
@@ -1153,8 +1163,9 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
       continue;
     }
 
+    const bool at_node = active && !(cur & CHILD_LEAF);
     // ---------------------------------------------------------------- one step per lane: a node ...
-    if (active && !(cur & CHILD_LEAF)) {
+    if (at_node) {
       if (COUNT) {
         n_nodes++;
         if (lane_rank(__ballot(1)) == 0) n_node_steps++;
@@ -1179,8 +1190,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
       const uint32_t nzw[2] = {ngz ? Q2.z : Q1.x, ngz ? Q2.w : Q1.y}, fzw[2] = {ngz ? Q1.x : Q2.z, ngz ? Q1.y : Q2.w};
       const uint32_t ch[8] = {C0.x, C0.y, C0.z, C0.w, C1.x, C1.y, C1.z, C1.w};
       const float far_limit = r.best_t;
-      uint32_t first = CHILD_EMPTY;
-      float first_key = MIRT_INF;
+      // All eight slab tests first (straight-line VALU), then the choice of the child to enter, then the pushes.  The kernel
+      // is bound by VALU issue (~3900 wave instructions per ray before this form, most of them exec-mask bookkeeping around
+      // eight conditional pushes with their LDS / overflow split): the common case - the lane's pushes all fit its LDS
+      // part of the stack - is one compare, one masked ds_write and one add per child.
+      float key[8];
+      uint32_t hits = 0;
 #pragma unroll
       for (int c = 0; c < 8; c++) {
         const int w = c >> 2, sh = 8 * (c & 3);
@@ -1191,15 +1206,34 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
         const float tmn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
         const float tmx = fminf(fminf(tfx, tfy), fminf(tfz, far_limit)) * SLACK;
         const bool hit = (ch[c] != CHILD_EMPTY) && (tmn <= tmx) && (tmx > r.min_t);
-        if (hit) {
-          // the nearest child is entered next, the others wait on the stack with their entry distance
-          if (ANY ? (first == CHILD_EMPTY) : (tmn < first_key || first == CHILD_EMPTY)) {
-            if (first != CHILD_EMPTY) push(first, first_key);
-            first = ch[c];
-            first_key = tmn;
-          } else {
-            push(ch[c], tmn);
-          }
+        key[c] = tmn;
+        hits |= hit ? (1u << c) : 0u;
+      }
+      // the child entered next: the nearest one hit (closest-hit rays), the first one hit (occlusion rays: any order will do)
+      uint32_t first = CHILD_EMPTY;
+      float first_key = MIRT_INF;
+      uint32_t first_bit = 0;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const bool better = ((hits >> c) & 1u) && (ANY ? (first_bit == 0u) : (first_bit == 0u || key[c] < first_key));
+        first = better ? ch[c] : first;
+        first_key = better ? key[c] : first_key;
+        first_bit = better ? (1u << c) : first_bit;
+      }
+      const uint32_t rest = hits & ~first_bit;             // the others wait on the stack with their entry distance
+      if (rest) {
+        if (sp + (int) __popc(rest) <= NSTK) {
+#pragma unroll
+          for (int c = 0; c < 8; c++)
+            if ((rest >> c) & 1u) {
+              if (ANY) lds_stack32[sp * TRACE_BLOCK + tid] = ch[c];
+              else lds_stack[sp * TRACE_BLOCK + tid] = make_uint2(ch[c], f2u(key[c]));
+              sp++;
+            }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; c++)
+            if ((rest >> c) & 1u) push(ch[c], key[c]);
         }
       }
       if (first != CHILD_EMPTY) enter(first);
@@ -1208,6 +1242,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
 
     // ---------------------------------------------------------------- ... or a primitive (lanes that just reached a leaf join in)
     if (active && cur != CHILD_EMPTY && (cur & CHILD_LEAF)) {
+      const float4 *tp = a.tris + 3 * (size_t) tri_i;
+      const float4 tq0 = tp[0], tq1 = tp[1], tq2 = tp[2];
       float t, by, bz;
       uint32_t flat;
       bool near = false;
@@ -1215,7 +1251,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
         n_tris++;
         if (lane_rank(__ballot(1)) == 0) n_tri_steps++;
       }
-      const bool acc = tri_test_near<SPH>(a.tris, a.verts, tri_i, r, r.best_t, NEAR, t, by, bz, flat, near);
+      const bool acc = tri_test_near<SPH>(tq0, tq1, tq2, a.verts, r, r.best_t, NEAR, t, by, bz, flat, near);
       tri_i++;
       tri_n--;
       if (near || (acc && !(fabsf(t) < MIRT_INF))) {

@@ -17,4 +17,5 @@ python3 tools/pmc_summary.py $OUT/p1 $OUT/p2 > $OUT/pmc_summary.csv
 find $OUT -name "*counter_collection.csv" -delete
 cat $OUT/kernel_stats.csv | cut -c1-160
 grep -E "FETCH_SIZE|WRITE_SIZE" $OUT/pmc_summary.csv | grep mirt
+python3 tools/traffic_json.py $OUT/pmc_summary.csv profiles/${TAG}_pmc_fetch_write.csv > $OUT/traffic.json
 cat $OUT/bench.json
