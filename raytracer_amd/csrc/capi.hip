@@ -721,7 +721,8 @@ int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, std::vec
     HIPCHK(hipEventRecord(tm.b, stream));
     timed->push_back(tm);
   }
-  if (traversal != 2) {
+  static const int skip_redo = getenv("MIRT_SKIP_REDO") ? atoi(getenv("MIRT_SKIP_REDO")) : 0;   // timing experiments only: WRONG results
+  if (traversal != 2 && !((skip_redo & 1) && any) && !((skip_redo & 2) && !any)) {
     t.redo = 1;
     HIPCHK(launch_trace(t, any, 2, 256, stream));
   }

@@ -590,14 +590,19 @@ __device__ __forceinline__ bool tri_test_near(const float4 q0, const float4 q1, 
 #define MIRT_ADMIT_K 1.0e-5f
 #endif
   constexpr float ADMIT_K = MIRT_ADMIT_K;
-  const float L = fabsf(e1.x) + fabsf(e1.y) + fabsf(e1.z) + fabsf(e2.x) + fabsf(e2.y) + fabsf(e2.z);   // >= every edge length
 #ifndef MIRT_ADMIT_LEVEL
 #define MIRT_ADMIT_LEVEL 3
 #endif
 #if MIRT_ADMIT_LEVEL == 0
   if (false) {
 #else
-  if (__builtin_expect(accept && !(fminf(bx, fminf(by, bz)) > (ADMIT_K * fabsf(rc)) * ((fabsf(t) + L) * L)), 0)) {
+  bool well_inside = true;
+  if (accept) {
+    asm volatile("" ::: "memory");                        // (keeps the pre-test inside the branch: most trips of an occlusion wave accept nothing)
+    const float L = fabsf(e1.x) + fabsf(e1.y) + fabsf(e1.z) + fabsf(e2.x) + fabsf(e2.y) + fabsf(e2.z);   // >= every edge length
+    well_inside = fminf(bx, fminf(by, bz)) > (ADMIT_K * fabsf(rc)) * ((fabsf(t) + L) * L);
+  }
+  if (__builtin_expect(!well_inside, 0)) {
 #endif
     const V3 vb = vadd(p1, e1), vc = vadd(p1, e2);
     V3 lo = mk(fminf(p1.x, fminf(vb.x, vc.x)), fminf(p1.y, fminf(vb.y, vc.y)), fminf(p1.z, fminf(vb.z, vc.z)));
