@@ -50,9 +50,10 @@ def parse():
                     help="N > 1: spp slices (default: the wavefront loop runs spp/N times fewer, full-size iterations; 0.83-0.97 "
                          "per-rank efficiency measured with tools/part_probe.py) or interleaved 8x8 tiles (bit-identical to one "
                          "GPU, but every iteration shrinks to 1/N of the rays: 0.23 at N = 8)")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=0,
                     help="sample streams per pixel in flight (mirt_options.streams): same samples, fewer and larger wavefront "
-                         "iterations; 1 = one path per pixel at a time, the reference's order of summation")
+                         "iterations; 1 = one path per pixel at a time, the reference's order of summation; 0 (default) = 8 when "
+                         "a rank renders at least 32 samples per pixel, else 4 (measured: tools/streams64.sh, tools/share_sweep.sh)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (what the driver runs); gloo = rehearsal of the N > 1 path on a box "
                          "with fewer GPUs than ranks: ranks share the GPUs and the buffers are summed through host memory")
@@ -141,6 +142,10 @@ def main():
     coll_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
 
     from raytracer_amd import capi, scenes
+
+    if args.streams == 0:
+        spp_rank = args.spp // world if (world > 1 and args.partition == "spp") else args.spp
+        args.streams = 8 if spp_rank >= 32 else 4
 
     capi.init(local_rank)
     sd, data_kind = scenes.workload(args.workload)             # objects/<name>.obj when present, else the stand-in of SURVEY 8(d)
