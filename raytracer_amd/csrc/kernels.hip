@@ -996,8 +996,16 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
 //   * one loop in which every lane advances by one node OR one triangle per trip ("if-if"): the while-while form left
 //     75 % of the lanes idle in the node loop on this tree (tools/count_frame.py).
 // The primitive test itself is the exact one (tri_test_near).  SPH: the scene has sphere primitives.
+#ifndef MIRT_TRACE_WAVES
+#define MIRT_TRACE_WAVES 0
+#endif
+#if MIRT_TRACE_WAVES
+#define MIRT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(MIRT_TRACE_WAVES, MIRT_TRACE_WAVES)))
+#else
+#define MIRT_TRACE_ATTR
+#endif
 template<bool ANY, bool COUNT, bool SPH>
-__global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
+__global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(TraceArgs a) {
   constexpr float NEAR = 1.0e-5f;
 #ifndef MIRT_SLACK
 #define MIRT_SLACK 2.5e-5f
@@ -1245,36 +1253,52 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace_fast(TraceArgs a) {
       else pop();
     }
 
-    // ---------------------------------------------------------------- ... or a primitive (lanes that just reached a leaf join in)
+    // ---------------------------------------------------------------- ... or up to LEAF_BATCH primitives of a leaf (lanes that
+    // just reached a leaf join in).  The records of a leaf are requested together - one memory round trip for the leaf
+    // instead of one per primitive - and tested in the leaf's order against the shrinking best_t, as one per trip would.
+#ifndef MIRT_LEAF_BATCH
+#define MIRT_LEAF_BATCH 1
+#endif
+#ifndef MIRT_LEAF_BATCH_ANY
+#define MIRT_LEAF_BATCH_ANY MIRT_LEAF_BATCH
+#endif
+    constexpr uint32_t LEAF_BATCH = ANY ? MIRT_LEAF_BATCH_ANY : MIRT_LEAF_BATCH;
     if (active && cur != CHILD_EMPTY && (cur & CHILD_LEAF)) {
       const float4 *tp = a.tris + 3 * (size_t) tri_i;
-      const float4 tq0 = tp[0], tq1 = tp[1], tq2 = tp[2];
-      float t, by, bz;
-      uint32_t flat;
-      bool near = false;
-      if (COUNT) {
-        n_tris++;
-        if (lane_rank(__ballot(1)) == 0) n_tri_steps++;
+      float4 tq[LEAF_BATCH][3];
+      const uint32_t n_batch = tri_n < LEAF_BATCH ? tri_n : LEAF_BATCH;
+#pragma unroll
+      for (uint32_t k = 0; k < LEAF_BATCH; k++) {
+        tq[k][0] = tq[k][1] = tq[k][2] = make_float4(0, 0, 0, 0);
+        if (k < n_batch) { tq[k][0] = tp[3 * k]; tq[k][1] = tp[3 * k + 1]; tq[k][2] = tp[3 * k + 2]; }
       }
-      const bool acc = tri_test_near<SPH>(tq0, tq1, tq2, a.verts, r, r.best_t, NEAR, t, by, bz, flat, near);
-      tri_i++;
-      tri_n--;
-      if (near || (acc && !(fabsf(t) < MIRT_INF))) {
-        // two candidates (or a candidate and a limit) too close to call, or an accepted NaN / inf hit
-        const uint32_t pos = wave_reserve(a.redo_count, 1);
-        a.redo_queue[pos] = r.id;
-        active = false;
-      } else {
-        if (acc) {
-          r.best_t = t; r.b1 = by; r.b2 = bz; r.best_idx = (int32_t) flat;
-          if (ANY) {
-            a.occ[r.id] = 1u;
-            if (a.any_t) a.any_t[r.id] = r.best_t;
+      if (COUNT && lane_rank(__ballot(1)) == 0) n_tri_steps++;
+#pragma unroll
+      for (uint32_t k = 0; k < LEAF_BATCH; k++) {
+        if (active && k < n_batch) {
+          float t, by, bz;
+          uint32_t flat;
+          bool near = false;
+          if (COUNT) n_tris++;
+          const bool acc = tri_test_near<SPH>(tq[k][0], tq[k][1], tq[k][2], a.verts, r, r.best_t, NEAR, t, by, bz, flat, near);
+          if (near || (acc && !(fabsf(t) < MIRT_INF))) {
+            // two candidates (or a candidate and a limit) too close to call, or an accepted NaN / inf hit
+            const uint32_t pos = wave_reserve(a.redo_count, 1);
+            a.redo_queue[pos] = r.id;
             active = false;
+          } else if (acc) {
+            r.best_t = t; r.b1 = by; r.b2 = bz; r.best_idx = (int32_t) flat;
+            if (ANY) {
+              a.occ[r.id] = 1u;
+              if (a.any_t) a.any_t[r.id] = r.best_t;
+              active = false;
+            }
           }
         }
-        if (active && tri_n == 0) pop();
       }
+      tri_i += n_batch;
+      tri_n -= n_batch;
+      if (active && tri_n == 0) pop();
     }
 
     // ---------------------------------------------------------------- ray finished
