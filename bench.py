@@ -172,6 +172,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    film = np.zeros((h, w, 3), np.int32)       # the caller's film buffer lives across frames, as the reference's sample_buffer does
+
     def step():
         # the one N > 1 code path (raytracer_amd/dist.py, rehearsed with gloo in tests/test_dist_cpu.py): partition options
         # for this rank -> libmirt -> ONE sum-reduce of the accumulation buffer onto rank 0
@@ -180,7 +182,7 @@ def main():
         if dist is not None:
             torch.cuda.synchronize()
         if rank == 0:
-            capi.tonemap(accum.data_ptr(), w, h)          # film in host memory
+            capi.tonemap(accum.data_ptr(), w, h, out=film)          # film in host memory
         return st
 
     for _ in range(args.warmup):

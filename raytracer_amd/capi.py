@@ -362,8 +362,12 @@ def bvh_build_host(pos, leaf_size=4, ptype=None):
                 fast_to_flat=fast_to_flat)
 
 
-def tonemap(accum_ptr, w, h):
-    rgb = np.zeros((h, w, 3), np.int32)
+def tonemap(accum_ptr, w, h, out=None):
+    """Film of an accumulation buffer as (h, w, 3) int32 in host memory.  `out`: a buffer to fill instead of a new array (the
+    reference's sample_buffer lives across frames too, renderer.cuh:61; a fresh 25 MB array costs its page faults per frame)."""
+    if out is not None and (out.shape != (h, w, 3) or out.dtype != np.int32 or not out.flags["C_CONTIGUOUS"]):
+        raise ValueError("out must be a C-contiguous (h, w, 3) int32 array")
+    rgb = np.zeros((h, w, 3), np.int32) if out is None else out
     _chk(load().mirt_tonemap(C.c_void_p(accum_ptr), C.c_uint32(w), C.c_uint32(h), _p(rgb)))
     return rgb
 

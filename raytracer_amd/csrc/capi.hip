@@ -88,6 +88,7 @@ struct Global {
   hipEvent_t film_ev[8] = {};
   uint32_t *h_counts = nullptr;          // host-mapped, coherent: MAX_PIPES x RING slots of HSLOT words, written by k_logic
   uint32_t *d_counts = nullptr;          // the same memory as the device sees it
+  uint32_t *h_tail = nullptr;            // pinned: a frame's control blocks (error flags) and ray statistics, copied before the frame's last event
   uint32_t seq = 0;                      // stamp of the last iteration issued (never 0)
   hipEvent_t ring_ev[MAX_PIPES][RING] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;    // first launch / accumulation buffer complete (render_ms)
@@ -122,6 +123,7 @@ enum {
   CTRL_WORDS = CTRL_ERR + CTR_STRIDE
 };
 constexpr int CTRL_BLOCKS = 3;                           // per pipe: iteration i uses block i % 3 and clears block (i + 1) % 3
+constexpr size_t TAIL_BYTES = (size_t) CTRL_BLOCKS * MAX_PIPES * CTRL_WORDS * 4 + MAX_PIPES * 16 * 8;   // Global::h_tail
 constexpr int HSLOT = 8;                                 // words per host ring slot: 5 queue counters, 2 spare, stamp
 
 // ---- mirt_trace_static: everything its kernels need beyond the caller's inputs and outputs lives in ONE file-scope device
@@ -227,6 +229,7 @@ int mirt_init(int device) {
   HIPCHK(hipHostMalloc((void **) &G.h_counts, MAX_PIPES * RING * QC_WORDS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
   memset(G.h_counts, 0, MAX_PIPES * RING * QC_WORDS * sizeof(uint32_t));
   HIPCHK(hipHostGetDevicePointer((void **) &G.d_counts, G.h_counts, 0));
+  HIPCHK(hipHostMalloc((void **) &G.h_tail, TAIL_BYTES, hipHostMallocDefault));
   for (auto &e: G.film_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(hipEventCreate(&G.ev0));
   HIPCHK(hipEventCreate(&G.ev1));
@@ -276,6 +279,8 @@ void mirt_shutdown(void) {
   if (G.ev1) (void) hipEventDestroy(G.ev1);
   if (G.ev_in) (void) hipEventDestroy(G.ev_in);
   if (G.h_counts) (void) hipHostFree(G.h_counts);
+  if (G.h_tail) (void) hipHostFree(G.h_tail);
+  G.h_tail = nullptr;
   if (G.h_film) (void) hipHostFree(G.h_film);
   for (auto e: G.film_ev) if (e) (void) hipEventDestroy(e);
   for (auto e: G.pool) (void) hipEventDestroy(e);
@@ -974,17 +979,17 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   }
   if (via_planes && part.n_slots)
     HIPCHK(launch_sum_planes(s->planes.as<float4>(), streams, w * h, (float4 *) accum_dev, accumulate ? 1 : 0, G.stream));
+  // error flags and ray statistics ride home behind the frame's last kernel, into pinned memory: no blocking copies after it
+  constexpr size_t CTRL_ALL = (size_t) CTRL_BLOCKS * MAX_PIPES * CTRL_WORDS * 4;
   HIPCHK(hipEventRecord(evB, G.stream));
-  HIPCHK(hipEventSynchronize(evB));
+  HIPCHK(hipMemcpyAsync(G.h_tail, ctrl, CTRL_ALL, hipMemcpyDeviceToHost, G.stream));
+  HIPCHK(hipMemcpyAsync((char *) G.h_tail + CTRL_ALL, s->ray_stats.p, MAX_PIPES * 16 * 8, hipMemcpyDeviceToHost, G.stream));
+  HIPCHK(hipStreamSynchronize(G.stream));
   uint32_t err = 0;
-  {
-    std::vector<uint32_t> blocks((size_t) CTRL_BLOCKS * MAX_PIPES * CTRL_WORDS);   // one copy for all the error flags
-    HIPCHK(hipMemcpy(blocks.data(), ctrl, blocks.size() * 4, hipMemcpyDeviceToHost));
-    for (int b = 0; b < CTRL_BLOCKS * MAX_PIPES; b++) err |= blocks[(size_t) b * CTRL_WORDS + CTRL_ERR];
-  }
+  for (int b = 0; b < CTRL_BLOCKS * MAX_PIPES; b++) err |= G.h_tail[(size_t) b * CTRL_WORDS + CTRL_ERR];
   float ms = 0;
   HIPCHK(hipEventElapsedTime(&ms, evA, evB));
-  drain.armed = false;                                                   // evB has completed: every stream has joined G.stream
+  drain.armed = false;                                                   // G.stream is idle and every other stream had joined it
   if (err) return fail(MIRT_E_LIMIT, "traversal stack overflow on the device (BVH too deep)");
   for (const Timed &t: timed) {
     float tms = 0;
@@ -994,7 +999,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   }
   if (stats) {
     unsigned long long rs[16 * MAX_PIPES] = {0};
-    HIPCHK(hipMemcpy(rs, s->ray_stats.p, sizeof rs, hipMemcpyDeviceToHost));
+    memcpy(rs, (const char *) G.h_tail + CTRL_ALL, sizeof rs);
     for (int p = 1; p < MAX_PIPES; p++)
       for (int k = 0; k < 16; k++) rs[k] += rs[16 * p + k];              // the pipes' counters
     memset(stats, 0, sizeof *stats);
