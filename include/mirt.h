@@ -223,10 +223,10 @@ int mirt_trace(mirt_scene *scene, const float *rays, uint32_t n, int any_hit, ui
  * code under HIP graph capture, tight serving loops, harnesses that forbid it.  rays_dev (n x 8 floats, as mirt_trace),
  * idx_dev and tbits_dev (n each) are DEVICE memory of the caller; results as mirt_trace (no barycentrics).  Every
  * intermediate (ray and hit records, queues, counters, the traversal's stack overflow region) lives in one static device
- * array of ~23 MB that each GPU the library runs on holds until the process ends; its address is looked up once per
- * device in mirt_init.  Limits, rejected with MIRT_E_LIMIT: n <= MIRT_TRACE_STATIC_MAX_RAYS; for traversals 0 and 1 a tree
- * whose traversal stack fits 72 entries per lane beyond the LDS part (all BASELINE workloads do; deep device-built radix
- * trees may not).  The call makes no hipMalloc / hipFree / hipHostMalloc and creates no stream or event; it is ordered after
+ * array of ~10 MB that each GPU the library runs on holds until the process ends; its address is looked up once per
+ * device in mirt_init.  Limit, rejected with MIRT_E_LIMIT: n <= MIRT_TRACE_STATIC_MAX_RAYS (a ray whose traversal stack
+ * outgrows the array's 24 entries per lane beyond the LDS part is finished by the reference walk, as in mirt_trace: any tree
+ * works).  The call makes no hipMalloc / hipFree / hipHostMalloc and creates no stream or event; it is ordered after
  * the device's NULL stream like mirt_render_accum and returns when idx_dev / tbits_dev are complete.  All calls on one GPU
  * share that GPU's array: calls that overlap on one GPU (two host threads) race and must be serialised by the caller. */
 #define MIRT_TRACE_STATIC_MAX_RAYS 65536u

@@ -83,6 +83,7 @@ struct Global {
   float table[256];
   bool table_exact = false;
   DevBuf d_table, d_rgb;
+  DevBuf ovf;                            // traversal-stack overflow regions (beyond the LDS part), kept across scenes: grows, never shrinks
   uint32_t *h_film = nullptr;            // pinned: the packed film on its way to the caller
   size_t h_film_words = 0;
   hipEvent_t film_ev[8] = {};
@@ -131,7 +132,7 @@ constexpr int HSLOT = 8;                                 // words per host ring 
 // name as an address: mirt_init asks the runtime for the address on the current device (hipGetSymbolAddress) and keeps it.
 constexpr uint32_t STATIC_MAX_RAYS = MIRT_TRACE_STATIC_MAX_RAYS;
 constexpr uint32_t STATIC_GRID = 128;                                    // workgroups of its traversal launches
-constexpr uint32_t STATIC_OVF_DEPTH = 72;                                // stack entries per lane beyond the LDS part
+constexpr uint32_t STATIC_OVF_DEPTH = 24;                                // stack entries per lane beyond the LDS part (deeper rays: k_redo)
 constexpr size_t align256(size_t v) { return (v + 255) & ~(size_t) 255; }
 constexpr size_t SO_CTRL = 0;
 constexpr size_t SO_RAY_O = align256(SO_CTRL + CTRL_WORDS * 4);
@@ -142,7 +143,7 @@ constexpr size_t SO_ANY_T = SO_OCC + (size_t) STATIC_MAX_RAYS * 4;
 constexpr size_t SO_QUEUE = SO_ANY_T + (size_t) STATIC_MAX_RAYS * 4;
 constexpr size_t SO_REDO = SO_QUEUE + (size_t) STATIC_MAX_RAYS * 4;
 constexpr size_t SO_OVF = SO_REDO + (size_t) STATIC_MAX_RAYS * 4;
-constexpr size_t SCRATCH_BYTES = SO_OVF + (size_t) STATIC_OVF_DEPTH * STATIC_GRID * TRACE_BLOCK * sizeof(uint2);   // ~ 23 MB
+constexpr size_t SCRATCH_BYTES = SO_OVF + (size_t) STATIC_OVF_DEPTH * STATIC_GRID * TRACE_BLOCK * sizeof(uint2);   // ~ 10 MB
 constexpr int MAX_DEVICES = 64;
 unsigned char *g_scratch_ptr[MAX_DEVICES] = {};                          // per device: its copy's address
 std::mutex g_scratch_mutex;
@@ -165,14 +166,14 @@ struct mirt_scene {
   uint32_t own_builder = 0;              // 0 host binned SAH, 1 device (build.hip)
   uint32_t n_nodes8 = 0, depth8 = 0;
   float build_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, ovf, big, trisf, nodes8q, verts;
+  DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, big, trisf, nodes8q, verts;
   uint32_t ovf_depth = 0;
   uint32_t trace_threads = 0;
   // work buffers (sized per render)
   DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2], mf_queue, live[2];
   DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t, planes;
   size_t device_bytes() const {
-    const DevBuf *all[] = {&verts, &nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
+    const DevBuf *all[] = {&verts, &nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                            &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0],
                            &redo_q[1], &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue, &planes, &live[0], &live[1]};
     size_t s = 0;
@@ -180,7 +181,7 @@ struct mirt_scene {
     return s;
   }
   void release_all() {
-    DevBuf *all[] = {&verts, &nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &ovf, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
+    DevBuf *all[] = {&verts, &nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                      &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0], &redo_q[1],
                      &ctrl, &ray_stats, &out_accum, &rgb, &probe_idx, &probe_t, &any_t, &mf_queue, &planes, &live[0], &live[1]};
     for (auto *b: all) b->release();
@@ -286,6 +287,7 @@ void mirt_shutdown(void) {
   for (auto e: G.pool) (void) hipEventDestroy(e);
   G.d_table.release();
   G.d_rgb.release();
+  G.ovf.release();
   for (int p = 0; p < MAX_PIPES; p++) if (G.pstream[p]) (void) hipStreamDestroy(G.pstream[p]);
   G = Global();
 }
@@ -493,10 +495,17 @@ static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const u
   }
   if (ok) {
     s->trace_threads = (uint32_t) (G.n_cu * G.blocks_per_cu * TRACE_BLOCK);
+    // Worst case of a nearest-first walk: every level leaves all its other children waiting (3 per level of the 4-wide tree,
+    // 7 of the 8-wide one).  Real rays stay far below that, and the region costs 8 B x resident lanes x launches in flight
+    // per level (~25 MB), so it is capped: a ray that outgrows LDS part + region is handed to the reference walk (k_redo),
+    // whose result is the reference's by construction.  MIRT_OVF_CAP: levels beyond the LDS part (default 24).
+    const int ovf_cap = getenv("MIRT_OVF_CAP") ? std::max(1, atoi(getenv("MIRT_OVF_CAP"))) : 24;
     int need = std::max(3 * ((int) s->bvh.depth4 + 2), 7 * ((int) s->depth8 + 2)) - LDS_STACK + 1;
+    need = std::min(need, ovf_cap);
     s->ovf_depth = (uint32_t) (need > 1 ? need : 1);
-    // one region per launch in flight: the closest-hit and the shadow launch of an iteration run concurrently, in each pipe
-    ok = s->ovf.ensure(2 * MAX_PIPES * (size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
+    // one region per launch in flight: the closest-hit and the shadow launch of an iteration run concurrently, in each pipe.
+    // The buffer belongs to the library context, not the scene: frame loops that rebuild the scene keep it.
+    ok = G.ovf.ensure(2 * MAX_PIPES * (size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
   }
   if (!ok) {
     rc = fail(MIRT_E_DEVICE, std::string("scene upload failed: ") + hipGetErrorString(hipGetLastError()));
@@ -678,7 +687,7 @@ TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal, int 
   t.qcap = n_slots;
   t.hit = s->hit.as<float4>() + off;
   t.work_head = ctrl + CTRL_WORK + 0;
-  t.ovf = s->ovf.as<uint2>() + (size_t) (2 * pipe) * s->ovf_depth * s->trace_threads;
+  t.ovf = G.ovf.as<uint2>() + (size_t) (2 * pipe) * s->ovf_depth * s->trace_threads;
   t.redo_queue = s->redo_q[0].as<uint32_t>() + off;
   t.redo_count = ctrl + CTRL_REDO + 0;
   t.error_flag = ctrl + CTRL_ERR;
@@ -698,7 +707,7 @@ TraceArgs shadow_args(mirt_scene *s, uint32_t traversal, int pipe = 0, size_t ko
   t.qc_back = -1;
   t.occ = s->sh_occ.as<uint32_t>() + koff;
   t.work_head = ctrl + CTRL_WORK + WORK_PARTS * CTR_STRIDE;
-  t.ovf = s->ovf.as<uint2>() + (size_t) (2 * pipe + 1) * s->ovf_depth * s->trace_threads;
+  t.ovf = G.ovf.as<uint2>() + (size_t) (2 * pipe + 1) * s->ovf_depth * s->trace_threads;
   t.redo_queue = s->redo_q[1].as<uint32_t>() + koff;
   t.redo_count = ctrl + CTRL_REDO + CTR_STRIDE;
   t.error_flag = ctrl + CTRL_ERR;
@@ -1222,9 +1231,6 @@ int mirt_trace_static(mirt_scene *s, const float *rays_dev, uint32_t n, int any_
   if (n > STATIC_MAX_RAYS)
     return fail(MIRT_E_LIMIT, "mirt_trace_static: more than MIRT_TRACE_STATIC_MAX_RAYS (65536) rays in one call");
   if (traversal == 0 && !s->fast_ok) traversal = 1;
-  if (traversal != 2 && s->ovf_depth > STATIC_OVF_DEPTH)
-    return fail(MIRT_E_LIMIT, "mirt_trace_static: the scene's tree is too deep for the static stack region (72 entries per "
-                              "lane beyond the LDS part); use mirt_trace or traversal 2");
   unsigned char *base = (G.device >= 0 && G.device < MAX_DEVICES) ? g_scratch_ptr[G.device] : nullptr;
   if (!base) return fail(MIRT_E_STATE, "mirt_trace_static: no scratch address for this device");
   if (n == 0) return MIRT_OK;
@@ -1243,6 +1249,7 @@ int mirt_trace_static(mirt_scene *s, const float *rays_dev, uint32_t n, int any_
   t.any_t = any_hit ? (float *) (base + SO_ANY_T) : nullptr;
   t.work_head = ctrl + CTRL_WORK;
   t.ovf = (uint2 *) (base + SO_OVF);
+  t.ovf_depth = std::min(s->ovf_depth, STATIC_OVF_DEPTH);               // (MIRT_OVF_CAP may exceed the static region's depth)
   t.redo_queue = (uint32_t *) (base + SO_REDO);
   t.redo_count = ctrl + CTRL_REDO;
   t.error_flag = ctrl + CTRL_ERR;

@@ -800,10 +800,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
   int sp = 0;
   uint32_t n_nodes = 0, n_tris = 0, n_node_steps = 0, n_tri_steps = 0;   // COUNT: work items and wave-level steps
 
+  // (a ray whose stack outgrows the LDS part + overflow region - the region is capped, capi.hip - is handed to the reference
+  // walk once the node step is over)
+  bool too_deep = false;
   auto push = [&](uint32_t ref, float tmn) {
     if (sp < LDS_STACK) lds_stack[sp * TRACE_BLOCK + tid] = make_uint2(ref, f2u(tmn));
     else if (sp < LDS_STACK + (int) a.ovf_depth) a.ovf[(size_t) (sp - LDS_STACK) * nthreads + gtid] = make_uint2(ref, f2u(tmn));
-    else { atomicOr(a.error_flag, 2u); return; }
+    else { too_deep = true; return; }
     sp++;
   };
   auto pop = [&]() {                                       // next node whose entry distance is still in range
@@ -918,6 +921,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
       }
       if (first != CHILD_EMPTY) cur = first;
       else pop();
+      if (too_deep) {
+        const uint32_t pos = wave_reserve(a.redo_count, 1);
+        a.redo_queue[pos] = r.id;
+        active = false;
+        too_deep = false;
+      }
     }
 
     // ---------------------------------------------------------------- leaf
@@ -1070,8 +1079,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
       tri_n = (ref >> LEAF_COUNT_SHIFT) & 15u;              // the SAH tree has no oversized leaves
     }
   };
-  // (a stack deeper than LDS + overflow region cannot happen for the tree the region was sized for; if it does, the entry
-  // lands on the last slot, the ray is flagged and the launch reports it once the ray ends)
+  // (a stack deeper than LDS part + overflow region - the region is capped, capi.hip: the entry lands on the last slot, the
+  // ray is flagged and handed to the reference walk at the end of the node step)
   // Occlusion rays never look at an entry's distance: their entries are 4 bytes, and twice as many fit the lane's LDS part.
   constexpr int NSTK = ANY ? 2 * LDS_STACK : LDS_STACK;
   uint32_t *lds_stack32 = (uint32_t *) lds_stack;
@@ -1251,6 +1260,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
       }
       if (first != CHILD_EMPTY) enter(first);
       else pop();
+      if (too_deep) {
+        const uint32_t pos = wave_reserve(a.redo_count, 1);
+        a.redo_queue[pos] = r.id;
+        active = false;
+        too_deep = false;
+      }
     }
 
     // ---------------------------------------------------------------- ... or up to LEAF_BATCH primitives of a leaf (lanes that
@@ -1303,10 +1318,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
 
     // ---------------------------------------------------------------- ray finished
     if (active && cur == CHILD_EMPTY) {
-      if (too_deep) {
-        atomicOr(a.error_flag, 2u);
-        too_deep = false;
-      }
       if (ANY) {
         a.occ[r.id] = 0u;
         if (a.any_t) a.any_t[r.id] = r.best_t;

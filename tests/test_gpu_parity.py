@@ -118,6 +118,43 @@ def test_overlapping_geometry_overflows_the_lds_stack(mirt, oracle):
     s.close()
 
 
+def test_capped_overflow_region_hands_deep_rays_to_the_reference_walk(mirt, oracle, monkeypatch):
+    """The global overflow region of the traversal stack is capped (MIRT_OVF_CAP levels beyond the LDS part, default 24): a
+    ray that outgrows it is finished by the reference walk (k_redo) instead of failing the launch.  With a cap of ONE level
+    on the all-overlapping soup most rays take that route in traversals 0 and 1, and every result still equals the oracle's."""
+    sc = scenes.random_soup(2000, 4, extent=0.3, tri_size=1.0).finalize()
+    oracle.load(sc)
+    monkeypatch.setenv("MIRT_OVF_CAP", "1")                    # read when the scene is created
+    s = mirt.Scene(sc)
+    monkeypatch.delenv("MIRT_OVF_CAP")
+    rays = random_rays(sc, 20000, 12, True)
+    ci, ct = oracle.trace(rays)
+    ai, _ = oracle.trace(rays, anyhit=True)
+    for trav in (0, 1):
+        gi, gt = s.trace(rays, traversal=trav)
+        assert (gi == ci).all() and (gt == ct).all(), f"closest, traversal {trav}: {(gi != ci).sum()} differ"
+        hi, _ = s.trace(rays, anyhit=True, traversal=trav)
+        assert (hi == ai).all(), f"any-hit, traversal {trav}"
+    import torch
+    # the cap bites: a rendered frame reports far more reference-walk rays than the same frame with the default region
+    sc2 = scenes.conference_scene(20000)
+    monkeypatch.setenv("MIRT_OVF_CAP", "1")
+    capped = mirt.Scene(sc2)
+    monkeypatch.delenv("MIRT_OVF_CAP")
+    plain = mirt.Scene(sc2)
+    w, h = 160, 90
+    a0 = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+    a1 = torch.zeros_like(a0)
+    kw = dict(spp=4, spl=1, batch=64, tol=0.0, depth=4, rng_mode=1, traversal=0)
+    st0 = plain.render_accum(w, h, a0.data_ptr(), **kw)
+    st1 = capped.render_accum(w, h, a1.data_ptr(), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(a0, a1)
+    assert st1["exact_fallback_rays"] > st0["exact_fallback_rays"], (st0["exact_fallback_rays"], st1["exact_fallback_rays"])
+    for x in (s, capped, plain):
+        x.close()
+
+
 def test_six_shadow_rays_per_hit(mirt, oracle):
     """3 lights x 2 samples per light: the generic shadow-fold and emission loops of k_logic (the bench has K = 2)."""
     sc = scenes.cornell_scene(1, "diffuse")
