@@ -196,7 +196,10 @@ struct Generator {
   // geometry/generator.cuh:98-180 with an own OBJ/MTL reader (the reference uses rapidobj, absent here: triangle order of
   // polygons with more than three vertices is a fan and is NOT pinned against rapidobj).  MTL -> BSDF rule: :126-148.
   // Divergences, documented: missing normals get the geometric normal (the reference reads out of bounds);
-  // faces without a material get a default diffuse instead of a null BSDF.
+  // faces without a material get a default diffuse instead of a null BSDF.  Defaults of a material's missing statements:
+  // zero colours, Ns = 1, Ni = 1, illum 0 - what rapidobj's default-constructed Material holds as far as we know (tinyobj
+  // semantics); rapidobj is not in /root/reference, so this is UNPINNED: the bundled .mtl files the tests read
+  // (tests/test_obj_ingest.py) spell out every statement the MTL -> BSDF rule looks at.
   static bool from_obj(std::vector<Primitive *> *prims, const std::string &file, BSDF *bsdf = nullptr,
                        Vector3f scale = {1, 1, 1}, Vector3f translate = {0, 0, 0}) {
     std::ifstream in(file);
@@ -204,7 +207,7 @@ struct Generator {
       std::printf("could not open %s\n", file.c_str());
       return false;
     }
-    struct Mtl { float Kd[3] = {1, 1, 1}, Ks[3] = {0, 0, 0}, Ke[3] = {0, 0, 0}, Tf[3] = {1, 1, 1}; float Ni = 1, Ns = 10; int illum = 0; };
+    struct Mtl { float Kd[3] = {0, 0, 0}, Ks[3] = {0, 0, 0}, Ke[3] = {0, 0, 0}, Tf[3] = {0, 0, 0}; float Ni = 1, Ns = 1; int illum = 0; };
     std::map<std::string, Mtl> mtls;
     std::map<std::string, BSDF *> made;
     std::vector<Vector3f> P, N;

@@ -541,10 +541,16 @@ struct Scratch {                                            // frees what the bu
 
 }  // namespace
 
+// (an early return must not leave copies in flight that target this function's stack variables, or kernels that use the
+// scratch the destructor of `sc` frees: the failure path drains the stream first)
 #define BCHK(expr)                                                                              \
   do {                                                                                          \
     hipError_t e_ = (expr);                                                                     \
-    if (e_ != hipSuccess) { res.error = std::string(#expr) + ": " + hipGetErrorString(e_); return -1; } \
+    if (e_ != hipSuccess) {                                                                     \
+      res.error = std::string(#expr) + ": " + hipGetErrorString(e_);                            \
+      (void) hipStreamSynchronize(stream);                                                      \
+      return -1;                                                                                \
+    }                                                                                           \
   } while (0)
 
 int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat_host, const void *tris_dev, uint32_t n,
@@ -661,7 +667,7 @@ int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat
       uint32_t m_next = 0;
       BCHK(hipMemcpyAsync(&m_next, d_m, 4, hipMemcpyDeviceToHost, stream));
       BCHK(hipStreamSynchronize(stream));
-      if (m_next == 0 || m_next >= m) { res.error = "PLOC made no progress"; return -1; }
+      if (m_next == 0 || m_next >= m) { res.error = "PLOC made no progress"; (void) hipStreamSynchronize(stream); return -1; }
       m = m_next;
     }
     res.passes = passes;
