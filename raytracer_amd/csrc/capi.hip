@@ -66,9 +66,9 @@ struct Global {
   int device = -1;
   int n_cu = 0;
   int blocks_per_cu = 2;
-  uint32_t refill_min = 8;
+  uint32_t refill_min = 16;             // MIRT_REFILL_MIN: idle lanes before a wave fetches rays (tools/env_sweep.sh at 8 streams: 8 -> 16, -1 %)
   bool serial = false;
-  uint32_t static_16th = 12;
+  uint32_t static_16th = 8;             // MIRT_STATIC_16TH: share of a queue handed out as per-workgroup slices (12 -> 8: -1.5 %; the rest is the balancing pool)
   // Two pipes: a frame with sample streams is rendered as two independent wavefront loops over halves of the slots, each
   // with its own pair of streams (main: k_logic + closest-hit traversal, side: shadow traversal), so that the HBM-bound
   // k_logic of one half runs while the other half is in its traversals.  `stream` / `side` are pipe 0's.
