@@ -1064,8 +1064,14 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
   }
   __syncthreads();
   const uint32_t psz = ((pool_total + WORK_PARTS - 1) / WORK_PARTS + 63u) & ~63u;     // pool positions per range
-  uint32_t chunk = (pool_total / (n_blk * (TRACE_BLOCK / 64) * 2u)) & ~31u;
-  chunk = chunk < 32u ? 32u : (chunk > 256u ? 256u : chunk);
+#ifndef MIRT_CHUNK_MAX
+#define MIRT_CHUNK_MAX 256u
+#endif
+#ifndef MIRT_CHUNK_DIV
+#define MIRT_CHUNK_DIV 2u
+#endif
+  uint32_t chunk = (pool_total / (n_blk * (TRACE_BLOCK / 64) * MIRT_CHUNK_DIV)) & ~31u;
+  chunk = chunk < 32u ? 32u : (chunk > MIRT_CHUNK_MAX ? MIRT_CHUNK_MAX : chunk);
   uint32_t w_next = 0, w_end = 0, part = blockIdx.x & (WORK_PARTS - 1), parts_tried = 0;
   bool slice_done = (per_blk == 0);
   bool wave_done = (total == 0);
