@@ -76,7 +76,7 @@ struct Global {
   hipStream_t pstream[MAX_PIPES] = {}, pside[MAX_PIPES] = {};
   hipEvent_t fork_ev[MAX_PIPES][RING] = {}, join_ev[MAX_PIPES][RING] = {};
   hipEvent_t pipe_ev[MAX_PIPES] = {};
-  int pipes = 2;                        // MIRT_PIPES: independent wavefront loops per frame (1, 2 or 4; needs as many sample streams)
+  int pipes = 2;                        // MIRT_PIPES: independent wavefront loops per frame (1 ... 4; needs as many sample streams)
   bool one_pipe = false;
   uint32_t live_16th = 4;               // MIRT_LIVE_16TH: k_logic walks the live-slot list once it is below this share of the slots
   bool blocks_forced = false;           // MIRT_BLOCKS_PER_CU given
@@ -244,7 +244,7 @@ int mirt_init(int device) {
   if (const char *s = getenv("MIRT_ONE_PIPE")) G.one_pipe = atoi(s) != 0;
   if (const char *s = getenv("MIRT_PIPES")) {
     const int v = atoi(s);
-    if (v == 1 || v == 2 || v == 4) G.pipes = v;
+    if (v >= 1 && v <= MAX_PIPES) G.pipes = v;
   }
   if (const char *s = getenv("MIRT_LIVE_16TH")) {
     int v = atoi(s);
