@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=0,
                     help="sample streams per pixel in flight (mirt_options.streams): same samples, fewer and larger wavefront "
                          "iterations; 1 = one path per pixel at a time, the reference's order of summation; 0 (default) = 8 when "
-                         "a rank renders at least 32 samples per pixel, else 4 (measured: tools/streams64.sh, tools/share_sweep.sh)")
+                         "a rank renders at least 16 samples per pixel, else 4 (measured: tools/streams64.sh, tools/share_sweep.sh)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (what the driver runs); gloo = rehearsal of the N > 1 path on a box "
                          "with fewer GPUs than ranks: ranks share the GPUs and the buffers are summed through host memory")
@@ -145,7 +145,7 @@ def main():
 
     if args.streams == 0:
         spp_rank = args.spp // world if (world > 1 and args.partition == "spp") else args.spp
-        args.streams = 8 if spp_rank >= 32 else 4
+        args.streams = 8 if spp_rank >= 16 else 4
 
     capi.init(local_rank)
     sd, data_kind = scenes.workload(args.workload)             # objects/<name>.obj when present, else the stand-in of SURVEY 8(d)
