@@ -1051,8 +1051,24 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
   // A launch with few rays (the tail of a frame, a small image) uses only as many workgroups as it has rays for, one ray
   // per lane; the others leave at once instead of queueing up at the pool counters (measured: 125 us -> ~20 us for a
   // launch of 4 k rays).
+  // With very few rays (the last iterations of a frame) the launch is pure latency: a wave takes as many trips as the
+  // longest of its rays, and every trip runs the node part and the primitive part if any lane needs them.  Such a launch
+  // is spread thin - 2, 4, ... 32 rays per wave, as few as the grid's waves allow, one batch per wave, no refill.
+#ifndef MIRT_THIN
+#define MIRT_THIN 1
+#endif
   __shared__ uint32_t s_next, s_dry;
-  const uint32_t want_blk = (total + TRACE_BLOCK - 1) / TRACE_BLOCK;
+  const uint32_t waves_all = gridDim.x * (TRACE_BLOCK / 64u);
+#ifndef MIRT_THIN_MIN
+#define MIRT_THIN_MIN 2u
+#endif
+  uint32_t thin_r = 0;
+  if (MIRT_THIN && total <= waves_all * 32u) {
+    thin_r = MIRT_THIN_MIN;
+    while (thin_r * waves_all < total) thin_r *= 2u;
+  }
+  const uint32_t per_wg = (TRACE_BLOCK / 64u) * (thin_r ? thin_r : 64u);   // rays a workgroup starts with
+  const uint32_t want_blk = (total + per_wg - 1u) / per_wg;
   const uint32_t n_blk = want_blk < gridDim.x ? (want_blk ? want_blk : 1u) : gridDim.x;
   if (blockIdx.x >= n_blk) return;
   const uint32_t per_blk = (uint32_t) (((uint64_t) total * a.static_16th / 16u) / n_blk) & ~63u;
@@ -1084,6 +1100,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
   uint32_t w_next = 0, w_end = 0, part = blockIdx.x & (WORK_PARTS - 1), parts_tried = 0;
   bool slice_done = (per_blk == 0);
   bool wave_done = (total == 0);
+  if (thin_r) {                                            // one batch: positions [wave * thin_r, + thin_r), then done
+    w_next = (gtid >> 6) * thin_r;
+    w_end = w_next + thin_r < total ? w_next + thin_r : total;
+    if (w_next >= total) { w_next = w_end = 0; wave_done = true; }
+    slice_done = true;
+    parts_tried = (uint32_t) WORK_PARTS;
+  }
   int sp = 0;
   uint32_t n_nodes = 0, n_tris = 0, n_node_steps = 0, n_tri_steps = 0;
 
