@@ -138,11 +138,6 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
   float4 acc4 = make_float4(0, 0, 0, 0);              // loaded when a sample is finished (once in a few iterations)
   float4 m4 = make_float4(0, 0, 0, 0), ro = m4, rd = m4, dm = m4, sc0 = m4, sc1 = m4;
   uint32_t occ0 = 1, occ1 = 1;
-  if (has_ray) {
-    m4 = a.mask[s];
-    ro = a.ray_o[s];
-    rd = a.ray_d[s];
-  }
   if (n_shadow) {
     dm = a.dmask[s];
     occ0 = a.sh_occ[s];
@@ -155,7 +150,10 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
   const int32_t prim = (int32_t) f2u(h.w);
   const bool shade = has_ray && prim >= 0;
   float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
-  if (shade) {
+  if (shade) {                                        // (a miss needs neither the ray nor the path's mask: 48 B less per miss)
+    m4 = a.mask[s];
+    ro = a.ray_o[s];
+    rd = a.ray_d[s];
     n0 = a.tri_nrm[3 * (size_t) prim];
     n1 = a.tri_nrm[3 * (size_t) prim + 1];
     n2 = a.tri_nrm[3 * (size_t) prim + 2];

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One frame of the bench workload at reduced spp, with no per-launch events: the program rocprofv3 wraps for PMC passes.
 
-    rocprofv3 --pmc <counters> -d gpurun_out/pmc_x -o x --output-format csv -- python3 tools/prof_frame.py [spp] [w] [h] [streams]
+    rocprofv3 --pmc <counters> -d gpurun_out/pmc_x -o x --output-format csv -- python3 tools/prof_frame.py [spp] [w] [h] [streams]     (WORKLOAD=bunny* ... picks another scene)
 """
 import os
 import sys
@@ -17,7 +17,7 @@ w = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
 streams = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 capi.init(0)
-sd = scenes.WORKLOADS["conference*"]()
+sd = scenes.WORKLOADS[os.environ.get("WORKLOAD", "conference*")]()
 sd.camera = sd.camera.for_aspect(w, h)
 scene = capi.Scene(sd)
 accum = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
