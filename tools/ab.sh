@@ -10,7 +10,8 @@ for rep in 1 2; do
 import json, sys
 d = json.load(open(sys.argv[1]))
 r = d["roofline"]
-print(f'{sys.argv[2]:28s} {d["ms_per_step"]:8.2f} ms  {d["value"]:8.0f} Mrays/s  closest launch {r["avg_launch_ms"]*1e3:6.1f} us  redo rays {d["config"].get("reference_walk_rays_per_frame", -1):.0f}', flush=True)
+k = r.get("kernels") or [{"avg_launch_ms": 0}] * 3
+print(f'{sys.argv[2]:28s} {d["ms_per_step"]:8.2f} ms  {d["value"]:8.0f} Mrays/s  closest launch {r["avg_launch_ms"]*1e3:6.1f} us  redo rays {d["config"].get("reference_walk_rays_per_frame", -1):.0f}  | split frame: closest {k[0]["avg_launch_ms"]*1e3:5.0f} any {k[1]["avg_launch_ms"]*1e3:5.0f} logic {k[2]["avg_launch_ms"]*1e3:5.0f} us', flush=True)
 PY
   done
 done
