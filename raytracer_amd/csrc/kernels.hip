@@ -125,45 +125,64 @@ typedef const float __attribute__((address_space(4))) *uniform_floats;
 // One slot, one iteration.  MF = false is the main kernel: it is compiled without the microfacet BSDF (whose double
 // precision pow/exp/tan/erf would set the register budget of every slot) and hands slots that hit such a material,
 // untouched, to the MF = true kernel through mf_queue.
+// The kernel's argument block again, read where it is used.  k_logic's RenderArgs is ~60 scalars (25 array pointers, the
+// camera, counts): read once at kernel entry they stay live through the whole slot function, far more than the 102 SGPRs
+// hold, and the compiler parks them in VGPR lanes (v_writelane / v_readlane + hazard nops: ~450 such instructions in the
+// kernel).  The late phases of logic_slot therefore read their fields through this reference: the same kernarg segment,
+// behind an opaque barrier, so that those scalar loads (scalar-cache hits) are issued next to their use.  Only valid in
+// a kernel whose first argument is the RenderArgs (k_logic).
+#ifndef MIRT_LATE_ARGS
+#define MIRT_LATE_ARGS 1
+#endif
+__device__ __forceinline__ const RenderArgs &late_args(const RenderArgs &entry) {
+#if MIRT_LATE_ARGS
+  auto p = __builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const RenderArgs *) p;
+#else
+  return entry;
+#endif
+}
+
 template<bool MF>
-__device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s, const uint4 st, Emit &em) {
+__device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t s, const uint4 st, Emit &em) {
   const uint32_t flags0 = st.z & 0xFF;
   uint32_t n_shadow = (st.z >> 8) & 0xFFFF;
   const bool has_ray = (flags0 & F_HAS_RAY) != 0;
 
   // ---- 0. every load this slot can need, issued in dependency order before anything waits on one of them
   float4 h = make_float4(0, 0, 0, u2f(0xFFFFFFFFu));
-  if (has_ray) h = a.hit[s];
-  const float4 tot4 = a.total[s];
+  if (has_ray) h = a0.hit[s];
+  const float4 tot4 = a0.total[s];
   float4 acc4 = make_float4(0, 0, 0, 0);              // loaded when a sample is finished (once in a few iterations)
   float4 m4 = make_float4(0, 0, 0, 0), ro = m4, rd = m4, dm = m4, sc0 = m4, sc1 = m4;
   uint32_t occ0 = 1, occ1 = 1;
   if (n_shadow) {
-    dm = a.dmask[s];
-    occ0 = a.sh_occ[s];
-    sc0 = a.sh_c[s];
+    dm = a0.dmask[s];
+    occ0 = a0.sh_occ[s];
+    sc0 = a0.sh_c[s];
     if (n_shadow > 1) {
-      occ1 = a.sh_occ[(size_t) a.n_slots + s];
-      sc1 = a.sh_c[(size_t) a.n_slots + s];
+      occ1 = a0.sh_occ[(size_t) a0.n_slots + s];
+      sc1 = a0.sh_c[(size_t) a0.n_slots + s];
     }
   }
   const int32_t prim = (int32_t) f2u(h.w);
   const bool shade = has_ray && prim >= 0;
   float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
   if (shade) {                                        // (a miss needs neither the ray nor the path's mask: 48 B less per miss)
-    m4 = a.mask[s];
-    ro = a.ray_o[s];
-    rd = a.ray_d[s];
-    n0 = a.tri_nrm[3 * (size_t) prim];
-    n1 = a.tri_nrm[3 * (size_t) prim + 1];
-    n2 = a.tri_nrm[3 * (size_t) prim + 2];
+    m4 = a0.mask[s];
+    ro = a0.ray_o[s];
+    rd = a0.ray_d[s];
+    n0 = a0.tri_nrm[3 * (size_t) prim];
+    n1 = a0.tri_nrm[3 * (size_t) prim + 1];
+    n2 = a0.tri_nrm[3 * (size_t) prim + 2];
   }
   DBsdf bsdf;
   bsdf.type = BSDF_DIFFUSE;
 #pragma unroll
   for (int k = 0; k < 8; k++) bsdf.p[k] = 0.f;
   if (shade) {
-    const float4 *mp = a.mats + 3 * (size_t) f2u(n2.y);
+    const float4 *mp = a0.mats + 3 * (size_t) f2u(n2.y);
     const float4 b0 = mp[0], b1 = mp[1], b2 = mp[2];
     bsdf.type = (int32_t) f2u(b0.x);
     bsdf.p[0] = b0.y; bsdf.p[1] = b0.z; bsdf.p[2] = b0.w;
@@ -171,11 +190,12 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a, const uint32_t s
     bsdf.p[7] = b2.x;
   }
   if (!MF && shade && bsdf.type == BSDF_MICROFACET) {
-    const uint32_t pos = wave_reserve(a.mf_count, 1);
-    a.mf_queue[pos] = s;
+    const uint32_t pos = wave_reserve(a0.mf_count, 1);
+    a0.mf_queue[pos] = s;
     return;
   }
 
+  const RenderArgs &a = late_args(a0);                 // from here on: fields read next to their use
   uint32_t px, py;
   bool valid;
   slot_to_pixel(a, s, px, py, valid);
