@@ -1298,7 +1298,25 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
         first_key = better ? key[c] : first_key;
         first_bit = better ? (1u << c) : first_bit;
       }
-      const uint32_t rest = hits & ~first_bit;             // the others wait on the stack with their entry distance
+      uint32_t rest = hits & ~first_bit;                   // the others wait on the stack with their entry distance
+#ifndef MIRT_FAR_FIRST
+#define MIRT_FAR_FIRST 0
+#endif
+      if (MIRT_FAR_FIRST && !ANY && (rest & (rest - 1u))) {      // two or more: the farthest goes deepest
+        uint32_t far_c = 0;
+        float far_key = -1.0f;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const bool f = ((rest >> c) & 1u) && key[c] > far_key;
+          far_key = f ? key[c] : far_key;
+          far_c = f ? (uint32_t) c : far_c;
+        }
+        uint32_t far_ref = ch[0];
+#pragma unroll
+        for (int c = 1; c < 8; c++) far_ref = far_c == (uint32_t) c ? ch[c] : far_ref;
+        push(far_ref, far_key);
+        rest &= ~(1u << far_c);
+      }
       if (rest) {
         if (sp + (int) __popc(rest) <= NSTK) {
 #pragma unroll
