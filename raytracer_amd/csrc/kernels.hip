@@ -16,6 +16,52 @@
 #include "kernels.hpp"
 #include "shade.hpp"
 
+// ============================================================================================ build-time knobs
+// -DNAME=value on the hipcc line (tools/build_variant.sh builds a variant library, tools/ab.sh compares them on one box).
+// The defaults are the measured best; what the other settings cost is in DESIGN.md 5.
+#ifndef MIRT_LATE_ARGS
+#define MIRT_LATE_ARGS 1   // k_logic's late phases read the argument block next to their use: 444 -> 22 SGPR spill instructions, 127 VGPR
+#endif
+#ifndef MIRT_LOGIC_WAVES
+#define MIRT_LOGIC_WAVES 0   // k_logic: amdgpu_waves_per_eu(min); 0 = the compiler's choice.  4..6 measured: nothing / slower (spills)
+#endif
+#ifndef MIRT_ADMIT_K
+#define MIRT_ADMIT_K 1.0e-5f   // own-box admission pre-test: barycentric margin factor
+#endif
+#ifndef MIRT_ADMIT_LEVEL
+#define MIRT_ADMIT_LEVEL 3   // own-box admission: 3 = the full test; 0 = off (timing experiments only: not exact)
+#endif
+#ifndef MIRT_TRACE_WAVES
+#define MIRT_TRACE_WAVES 0   // k_trace_fast: amdgpu_waves_per_eu(n, n); 0 = the compiler's choice (72 VGPR, 7 waves).  8: spills, +13 %
+#endif
+#ifndef MIRT_SLACK
+#define MIRT_SLACK 2.5e-5f   // relative slack of the distance pruning (triangle scenes).  1e-3: +2 %
+#endif
+#ifndef MIRT_THIN
+#define MIRT_THIN 1   // launches with very few rays spread thin over the grid's waves (tail launches 124 -> 90 us)
+#endif
+#ifndef MIRT_THIN_MIN
+#define MIRT_THIN_MIN 2u   // fewest rays per wave of a thin launch
+#endif
+#ifndef MIRT_XCD_SLICES
+#define MIRT_XCD_SLICES 0   // XCD x takes the x-th eighth of the per-workgroup slices.  Measured: nothing
+#endif
+#ifndef MIRT_CHUNK_MAX
+#define MIRT_CHUNK_MAX 256u   // largest pool fetch of a wave, in rays.  64 ... 1024: within noise
+#endif
+#ifndef MIRT_CHUNK_DIV
+#define MIRT_CHUNK_DIV 2u   // pool fetches per wave the pool is sized for
+#endif
+#ifndef MIRT_FAR_FIRST
+#define MIRT_FAR_FIRST 0   // closest-hit rays push the farthest waiting child first: -2 % node visits, no time gain
+#endif
+#ifndef MIRT_LEAF_BATCH
+#define MIRT_LEAF_BATCH 1   // primitives of a leaf requested and tested per trip.  2: +4 % (74-78 VGPR), 3: +15 % (90 VGPR)
+#endif
+#ifndef MIRT_LEAF_BATCH_ANY
+#define MIRT_LEAF_BATCH_ANY MIRT_LEAF_BATCH   // the same for the occlusion kernel
+#endif
+
 namespace mirt {
 
 // ============================================================================================ helpers
@@ -131,9 +177,6 @@ typedef const float __attribute__((address_space(4))) *uniform_floats;
 // kernel).  The late phases of logic_slot therefore read their fields through this reference: the same kernarg segment,
 // behind an opaque barrier, so that those scalar loads (scalar-cache hits) are issued next to their use.  Only valid in
 // a kernel whose first argument is the RenderArgs (k_logic).
-#ifndef MIRT_LATE_ARGS
-#define MIRT_LATE_ARGS 1
-#endif
 __device__ __forceinline__ const RenderArgs &late_args(const RenderArgs &entry) {
 #if MIRT_LATE_ARGS
   auto p = __builtin_amdgcn_kernarg_segment_ptr();
@@ -395,9 +438,6 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t 
 // Queue positions are reserved once per workgroup and queue (three atomics, each on a line of its own): a slot that is
 // not finished always leaves a ray in one of the queues, so the queue counters double as the "anything left?" test and
 // as the ray statistics (the host adds them up per iteration).
-#ifndef MIRT_LOGIC_WAVES
-#define MIRT_LOGIC_WAVES 0
-#endif
 #if MIRT_LOGIC_WAVES
 #define MIRT_LOGIC_ATTR __attribute__((amdgpu_waves_per_eu(MIRT_LOGIC_WAVES)))
 #else
@@ -604,13 +644,7 @@ __device__ __forceinline__ bool tri_test_near(const float4 q0, const float4 q1, 
   //    exact vertex) shrunk by 4e-7 relative per side, except along axes in which the triangle is exactly flat (e1 = e2 = 0
   //    there: the coordinate is exact).  Monotonicity again: what the smaller box admits, the exact one admits.
   // 3. Otherwise (a hit on the rim of the box; an axis too thin to shrink): the exact vertices from memory.
-#ifndef MIRT_ADMIT_K
-#define MIRT_ADMIT_K 1.0e-5f
-#endif
   constexpr float ADMIT_K = MIRT_ADMIT_K;
-#ifndef MIRT_ADMIT_LEVEL
-#define MIRT_ADMIT_LEVEL 3
-#endif
 #if MIRT_ADMIT_LEVEL == 0
   if (false) {
 #else
@@ -1023,9 +1057,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
 //   * one loop in which every lane advances by one node OR one triangle per trip ("if-if"): the while-while form left
 //     75 % of the lanes idle in the node loop on this tree (tools/count_frame.py).
 // The primitive test itself is the exact one (tri_test_near).  SPH: the scene has sphere primitives.
-#ifndef MIRT_TRACE_WAVES
-#define MIRT_TRACE_WAVES 0
-#endif
 #if MIRT_TRACE_WAVES
 #define MIRT_TRACE_ATTR __attribute__((amdgpu_waves_per_eu(MIRT_TRACE_WAVES, MIRT_TRACE_WAVES)))
 #else
@@ -1034,9 +1065,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
 template<bool ANY, bool COUNT, bool SPH>
 __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(TraceArgs a) {
   constexpr float NEAR = 1.0e-5f;
-#ifndef MIRT_SLACK
-#define MIRT_SLACK 2.5e-5f
-#endif
   // Scenes with spheres: the reference's sphere test (primitives.cuh:111-136) forms c = a.a - b*b, which cancels
   // catastrophically for a sphere far from the ray's origin: |error of c| <~ 4 eps |a|^2, so the computed hit - the one the
   // reference works with - can sit up to sqrt(4 eps) |a| = 4.9e-4 |a| beside or in front of the true sphere and of its
@@ -1072,14 +1100,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
   // With very few rays (the last iterations of a frame) the launch is pure latency: a wave takes as many trips as the
   // longest of its rays, and every trip runs the node part and the primitive part if any lane needs them.  Such a launch
   // is spread thin - 2, 4, ... 32 rays per wave, as few as the grid's waves allow, one batch per wave, no refill.
-#ifndef MIRT_THIN
-#define MIRT_THIN 1
-#endif
   __shared__ uint32_t s_next, s_dry;
   const uint32_t waves_all = gridDim.x * (TRACE_BLOCK / 64u);
-#ifndef MIRT_THIN_MIN
-#define MIRT_THIN_MIN 2u
-#endif
   uint32_t thin_r = 0;
   if (MIRT_THIN && total <= waves_all * 32u) {
     thin_r = MIRT_THIN_MIN;
@@ -1095,9 +1117,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
   // that region's part of the tree instead of all of it.  Measured: nothing (121.6 vs 121.8 ms; the tree lives in the
   // Infinity Cache and its latency is hidden as well as an L2 hit's), so the plain order stays.  (The pool ranges are per
   // XCD either way: a workgroup starts at range blockIdx % 8.)
-#ifndef MIRT_XCD_SLICES
-#define MIRT_XCD_SLICES 0
-#endif
   const uint32_t vblk = (MIRT_XCD_SLICES && (n_blk & 7u) == 0u) ? (blockIdx.x & 7u) * (n_blk >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const uint32_t slice_end = (vblk + 1) * per_blk;
   const uint32_t pool_lo = n_blk * per_blk, pool_total = total - pool_lo;
@@ -1107,12 +1126,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
   }
   __syncthreads();
   const uint32_t psz = ((pool_total + WORK_PARTS - 1) / WORK_PARTS + 63u) & ~63u;     // pool positions per range
-#ifndef MIRT_CHUNK_MAX
-#define MIRT_CHUNK_MAX 256u
-#endif
-#ifndef MIRT_CHUNK_DIV
-#define MIRT_CHUNK_DIV 2u
-#endif
   uint32_t chunk = (pool_total / (n_blk * (TRACE_BLOCK / 64) * MIRT_CHUNK_DIV)) & ~31u;
   chunk = chunk < 32u ? 32u : (chunk > MIRT_CHUNK_MAX ? MIRT_CHUNK_MAX : chunk);
   uint32_t w_next = 0, w_end = 0, part = blockIdx.x & (WORK_PARTS - 1), parts_tried = 0;
@@ -1299,9 +1312,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
         first_bit = better ? (1u << c) : first_bit;
       }
       uint32_t rest = hits & ~first_bit;                   // the others wait on the stack with their entry distance
-#ifndef MIRT_FAR_FIRST
-#define MIRT_FAR_FIRST 0
-#endif
       if (MIRT_FAR_FIRST && !ANY && (rest & (rest - 1u))) {      // two or more: the farthest goes deepest
         uint32_t far_c = 0;
         float far_key = -1.0f;
@@ -1345,12 +1355,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
     // ---------------------------------------------------------------- ... or up to LEAF_BATCH primitives of a leaf (lanes that
     // just reached a leaf join in).  The records of a leaf are requested together - one memory round trip for the leaf
     // instead of one per primitive - and tested in the leaf's order against the shrinking best_t, as one per trip would.
-#ifndef MIRT_LEAF_BATCH
-#define MIRT_LEAF_BATCH 1
-#endif
-#ifndef MIRT_LEAF_BATCH_ANY
-#define MIRT_LEAF_BATCH_ANY MIRT_LEAF_BATCH
-#endif
     constexpr uint32_t LEAF_BATCH = ANY ? MIRT_LEAF_BATCH_ANY : MIRT_LEAF_BATCH;
     if (active && cur != CHILD_EMPTY && (cur & CHILD_LEAF)) {
       const float4 *tp = a.tris + 3 * (size_t) tri_i;
