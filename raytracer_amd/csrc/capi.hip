@@ -162,6 +162,7 @@ struct mirt_scene {
   uint32_t n_tris = 0, n_mats = 0, n_lights = 0;
   bool has_microfacet = false;
   bool has_spheres = false;
+  float sph_rmin = 0.f;                  // smallest sphere radius (sphere scenes)
   bool fast_ok = true;                   // false: the SAH tree could not be built (non-finite vertices): traversal 0 runs as 1
   uint32_t own_builder = 0;              // 0 host binned SAH, 1 device (build.hip)
   uint32_t n_nodes8 = 0, depth8 = 0;
@@ -406,6 +407,12 @@ static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const u
   }
   });
   s->has_spheres = sphere_seen.load();
+  if (s->has_spheres) {
+    float rmin = std::numeric_limits<float>::infinity();
+    for (uint32_t i = 0; i < n_tris; i++)
+      if (prim_type[i] == 1) rmin = std::min(rmin, std::fabs(tri_pos[9 * (size_t) i + 3]));
+    s->sph_rmin = std::isfinite(rmin) ? rmin : 0.f;
+  }
   // the ordered traversal's own tree over the same primitives, in its own order: binned SAH on the host, or the device builder
   std::vector<float> trif;
   std::vector<float> flat_pos((size_t) n_tris * 9);
@@ -668,6 +675,7 @@ TraceArgs common_args(mirt_scene *s, uint32_t traversal) {
   t.nodes8 = s->nodes8q.p;
   t.verts = s->verts.as<float>();
   t.spheres = s->has_spheres ? 1 : 0;
+  t.sph_rmin = s->sph_rmin;
   t.refill_min = G.refill_min;
   t.static_16th = G.static_16th;
   t.big = s->big.as<uint2>();

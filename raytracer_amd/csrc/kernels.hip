@@ -37,6 +37,12 @@
 #ifndef MIRT_SLACK
 #define MIRT_SLACK 2.5e-5f   // relative slack of the distance pruning (triangle scenes).  1e-3: +2 %
 #endif
+#ifndef MIRT_SLACK_SPH
+#define MIRT_SLACK_SPH 2.5e-5f   // the same for sphere scenes (their boxes are dilated instead, k_trace_fast); 1.2e-3 until round 2
+#endif
+#ifndef MIRT_SPH_LATERAL
+#define MIRT_SPH_LATERAL 9.5e-4f   // sphere scenes: sqrt of the relative error bound of c = a.a - b*b, 15 x 2^-24 (k_trace_fast)
+#endif
 #ifndef MIRT_THIN
 #define MIRT_THIN 1   // launches with very few rays spread thin over the grid's waves (tail launches 124 -> 90 us)
 #endif
@@ -1065,14 +1071,18 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
 template<bool ANY, bool COUNT, bool SPH>
 __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(TraceArgs a) {
   constexpr float NEAR = 1.0e-5f;
-  // Scenes with spheres: the reference's sphere test (primitives.cuh:111-136) forms c = a.a - b*b, which cancels
-  // catastrophically for a sphere far from the ray's origin: |error of c| <~ 4 eps |a|^2, so the computed hit - the one the
-  // reference works with - can sit up to sqrt(4 eps) |a| = 4.9e-4 |a| beside or in front of the true sphere and of its
-  // bounding box (0.15 units at the 350 units of the reference app's camera, for spheres of radius 0.2).  A traversal that
-  // prunes with the true boxes would never test such a sphere while the reference, whose leaf boxes are unions over other
-  // spheres, may.  So for these scenes the box test is dilated by that much and distance pruning slackened accordingly.
-  constexpr float SPH_LATERAL = 6.0e-4f;
-  constexpr float SLACK = SPH ? 1.0f + 1.2e-3f : 1.0f + MIRT_SLACK;
+  // Scenes with spheres: the reference's sphere test (primitives.cuh:111-136) forms c = a.a - b*b with a = centre - origin,
+  // which cancels catastrophically for a sphere far from the ray's origin.  With u = 2^-24: the three subtractions of a, the
+  // products and sums of a.a (5u |a|^2), of b = a.d (4u |a|) and b*b (9u |a|^2) and the final subtraction (u |a|^2) put the
+  // computed c within 15u |a|^2 of the true one - SPH_LATERAL^2 = (9.5e-4)^2 > 15u.  The hit the reference works with,
+  // o + t d with t = b -+ sqrt(r^2 - c), then lies within sqrt(r^2 + 15u |a|^2) of the centre instead of r: up to 0.18 units
+  // outside a sphere of radius 0.2 seen from the 350 units of the reference app's camera, beside or in front of the
+  // sphere's bounding box.  A traversal that prunes with the true boxes would never test such a sphere while the
+  // reference, whose leaf boxes are unions over other spheres, may.  So for these scenes every box is dilated by that
+  // much (node step below); with the hit inside the dilated box, distance pruning needs no slack of its own.
+  // tools/soak_spheres.py: constants of 2e-4 / 3e-4 / 4e-4 leave 35 / 4 / 0.25 differences per million queries.
+  constexpr float SPH_LATERAL = MIRT_SPH_LATERAL;
+  constexpr float SLACK = SPH ? 1.0f + MIRT_SLACK_SPH : 1.0f + MIRT_SLACK;
   constexpr float AXIS_EPS = 4.76837158e-7f;              // 2^-21
   constexpr float INV_LIMIT = 1.0e15f;                    // steeper than this against an axis: reference walk
 
@@ -1267,10 +1277,19 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
                   sz = u2f(((H.w >> 16) & 0xFFu) << 23) * r.inv.z;
       const float bx = (u2f(H.x) - r.o.x) * r.inv.x, by_ = (u2f(H.y) - r.o.y) * r.inv.y, bz_ = (u2f(H.z) - r.o.z) * r.inv.z;
       float ex = AXIS_EPS * fabsf(bx), ey = AXIS_EPS * fabsf(by_), ez = AXIS_EPS * fabsf(bz_);
-      if (SPH) {                                           // lateral dilation by SPH_LATERAL x (distance bound to anything in the node)
-        const float reach = fabsf(u2f(H.x) - r.o.x) + fabsf(u2f(H.y) - r.o.y) + fabsf(u2f(H.z) - r.o.z) +
-                            255.0f * (u2f((H.w & 0xFFu) << 23) + u2f(((H.w >> 8) & 0xFFu) << 23) + u2f(((H.w >> 16) & 0xFFu) << 23));
-        const float m = SPH_LATERAL * reach;
+      if (SPH) {                                           // dilation by what the reference's sphere arithmetic can be off (see above)
+        // |a| <= distance from the origin to the farthest corner of the node's box, for every sphere centre in the node
+        const float wx = 255.0f * u2f((H.w & 0xFFu) << 23), wy = 255.0f * u2f(((H.w >> 8) & 0xFFu) << 23),
+                    wz = 255.0f * u2f(((H.w >> 16) & 0xFFu) << 23);
+        const float fx = fmaxf(fabsf(u2f(H.x) - r.o.x), fabsf(u2f(H.x) + wx - r.o.x)),
+                    fy = fmaxf(fabsf(u2f(H.y) - r.o.y), fabsf(u2f(H.y) + wy - r.o.y)),
+                    fz = fmaxf(fabsf(u2f(H.z) - r.o.z), fabsf(u2f(H.z) + wz - r.o.z));
+        const float reach2 = (fx * fx + fy * fy + fz * fz) * 1.00001f;
+        // sd2 bounds the error of c; a computed hit then lies within sqrt(r^2 + sd2) of the sphere's centre, so the box of a
+        // sphere of radius r has to grow by sqrt(r^2 + sd2) - r = sd2 / (sqrt(r^2 + sd2) + r) on every side: most for the
+        // smallest sphere of the scene (r = 0: by sqrt(sd2))
+        const float sd2 = (SPH_LATERAL * SPH_LATERAL) * reach2, rm = a.sph_rmin;
+        const float m = sd2 * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(rm * rm + sd2) + rm + 1.0e-30f) * 1.0001f;
         ex += m * fabsf(r.inv.x); ey += m * fabsf(r.inv.y); ez += m * fabsf(r.inv.z);
       }
       const float cnx = bx - ex, cny = by_ - ey, cnz = bz_ - ez, cfx = bx + ex, cfy = by_ + ey, cfz = bz_ + ez;

@@ -68,6 +68,7 @@ struct TraceArgs {
   uint32_t refill_min;                    // k_trace_fast: idle lanes a wave collects before it fetches new rays
   uint32_t static_16th;                   // k_trace_fast: sixteenths of the queue handed out as per-workgroup slices
   uint32_t spheres;                       // the scene has sphere primitives (selects the kernel instantiation)
+  float sph_rmin;                         // smallest sphere radius of the scene (0: unknown): bounds the box dilation of sphere scenes
   const float4 *nodes2;                   // 2 float4 per reference node
   const float4 *tris;                     // triangles in the order of the tree k_trace4 walks: p1, e1, e2, flat index
   const float4 *tris2;                    // triangles in the reference's flat order (k_trace2)
