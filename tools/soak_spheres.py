@@ -14,8 +14,6 @@ import numpy as np  # noqa: E402
 
 from raytracer_amd import capi, scenes  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
-capi.init(0)
 
 
 def cloud(n, radii, seed, spread=18.0):
@@ -70,25 +68,32 @@ def rays_for(sc, n, seed, dist):
     return r
 
 
-bad = 0
-for name, sc, dist in (("r=0.2 from 350", cloud(20000, [0.2], 5), 350.0), ("r=0.2 from 3000", cloud(20000, [0.2], 6), 3000.0),
-                       ("mixed radii 0.01-2 from 350", cloud(20000, [0.01, 0.05, 0.2, 2.0], 7), 350.0),
-                       ("200k spheres from 350", cloud(200000, [0.2], 8, spread=40.0), 350.0),
-                       ("r=0.2 from 20", cloud(20000, [0.2], 9), 20.0)):
-    for builder in ("host", "ploc"):
-        s = capi.Scene(sc, builder=builder)
-        diff = tot = hits = 0
-        for seed in range(max(1, N // 500000)):
-            rays = rays_for(sc, min(N, 500000), 100 + seed, dist)
-            ri, rt = s.trace(rays, traversal=2)
-            gi, gt = s.trace(rays, traversal=0)
-            ra, _ = s.trace(rays, anyhit=True, traversal=2)
-            ga, _ = s.trace(rays, anyhit=True, traversal=0)
-            diff += int(((ri != gi) | (rt != gt)).sum() + (ra != ga).sum())
-            tot += 2 * len(rays)
-            hits += int((ri >= 0).sum())
-        bad += diff
-        print(f"{name:30s} {builder:6s} {tot:9d} queries: {diff} differences, hit rate {hits / (tot / 2):.2f}", flush=True)
-        s.close()
-print("TOTAL differences:", bad)
-sys.exit(1 if bad else 0)
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    capi.init(0)
+    bad = 0
+    for name, sc, dist in (("r=0.2 from 350", cloud(20000, [0.2], 5), 350.0), ("r=0.2 from 3000", cloud(20000, [0.2], 6), 3000.0),
+                           ("mixed radii 0.01-2 from 350", cloud(20000, [0.01, 0.05, 0.2, 2.0], 7), 350.0),
+                           ("200k spheres from 350", cloud(200000, [0.2], 8, spread=40.0), 350.0),
+                           ("r=0.2 from 20", cloud(20000, [0.2], 9), 20.0)):
+        for builder in ("host", "ploc"):
+            s = capi.Scene(sc, builder=builder)
+            diff = tot = hits = 0
+            for seed in range(max(1, N // 500000)):
+                rays = rays_for(sc, min(N, 500000), 100 + seed, dist)
+                ri, rt = s.trace(rays, traversal=2)
+                gi, gt = s.trace(rays, traversal=0)
+                ra, _ = s.trace(rays, anyhit=True, traversal=2)
+                ga, _ = s.trace(rays, anyhit=True, traversal=0)
+                diff += int(((ri != gi) | (rt != gt)).sum() + (ra != ga).sum())
+                tot += 2 * len(rays)
+                hits += int((ri >= 0).sum())
+            bad += diff
+            print(f"{name:30s} {builder:6s} {tot:9d} queries: {diff} differences, hit rate {hits / (tot / 2):.2f}", flush=True)
+            s.close()
+    print("TOTAL differences:", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
