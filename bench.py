@@ -7,19 +7,27 @@ and tonemapped into host memory.  With N > 1 the frame is split over the ranks b
 (pixel, sample) is independent) or by interleaved 8x8 tiles (`--partition tile`), one process per GPU, `torch.distributed`
 over RCCL; the only collective is the sum-reduce of the accumulation buffer.
 
-    python bench.py [--gpus N --steps K --warmup W]       # N > 1: launched under torch.distributed.run by the driver
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: the driver launches this file under `torch.distributed.run` (WORLD_SIZE set: every rank checks WORLD_SIZE == --gpus).
+Started plainly with `--gpus N` and no WORLD_SIZE, the process launches those N ranks itself -- as children, BEFORE it makes
+any GPU call (it never imports torch) -- waits for them and relays rank 0's JSON line.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the closest-hit wide-BVH traversal) against HBM
 peak: algorithmic bytes = rays x (160 B of wavefront state + node visits x 96 B + triangle tests x 48 B),
-time = that kernel's launches measured with HIP events on its own stream inside the timed steps.  `cpu_baseline` times the
-reference's own CPU path (oracle/_ref, built from /root/reference in the build container) -- or the C oracle when that
-library is absent -- on a bounded crop of the same workload, on the box's host cores.
+time = that kernel's launches measured with HIP events on its own stream inside the timed steps; `roofline.kernels` prices
+all three hot kernels, `roofline.frame` adds up the measured HBM traffic of the whole frame, `roofline.sq` quotes the issue /
+lane / wait fractions of the traversal kernels from the committed counter passes (profiles/r3_pmc_sq.json).
+`cpu_baseline` times the reference's own CPU path (oracle/_ref, built from /root/reference in the build container) -- or the
+C oracle when that library is absent -- on a bounded crop of the same workload, on the box's host cores.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,7 +42,7 @@ S_NODE = {0: 96, 1: 128, 2: 32}  # bytes of one node: quantised 8-wide (traversa
 S_TRI = 48                     # bytes of one packed triangle (p1, e1, e2)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -64,23 +72,125 @@ def parse():
                          "the headline counts the rays the reference's control flow traces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ N > 1 launch
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, script, argv):
+    """`--gpus N` without WORLD_SIZE: start the N ranks as CHILD processes (torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1) from this process, which has made no GPU call and makes none; relay their output (rank 0 prints
+    the JSON line) and return their exit code.  Never a re-exec of a process that has touched the GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for ln in proc.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+# ------------------------------------------------------------------------------------------------ the renderer behind a step
+class GpuBackend:
+    """libmirt on this rank's GPU: the only renderer bench.py has (no CPU path).  tests/bench_stub_main.py substitutes a
+    stand-in with this interface to exercise the launch / partition / reduce plumbing on a box without GPUs."""
+
+    def __init__(self, args, rank, local_rank, world):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+        n_dev = torch.cuda.device_count()
+        if args.backend == "gloo":
+            local_rank %= n_dev
+        elif local_rank >= n_dev:
+            raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU of its own ({n_dev} visible); "
+                             "use --backend gloo to rehearse more ranks than GPUs")
+        torch.cuda.set_device(local_rank)
+        self.torch = torch
+        self.device = f"cuda:{local_rank}"
+        self.local_rank = local_rank
+        self.args = args
+
+    def init_process_group(self, dist):
+        if self.args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=self.torch.device("cuda", self.local_rank))
+        else:
+            dist.init_process_group("gloo")
+
+    def setup(self):
+        from raytracer_amd import capi, scenes
+
+        args = self.args
+        self.capi = capi
+        capi.init(self.local_rank)
+        sd, self.data_kind = scenes.workload(args.workload)         # objects/<name>.obj when present, else the stand-in of SURVEY 8(d)
+        sd.camera = sd.camera.for_aspect(args.width, args.height)
+        self.sd = sd
+        t0 = time.time()
+        self.scene = capi.Scene(sd, builder=args.builder)
+        self.build_s = time.time() - t0
+        self.build_ms = {k: round(v, 2) for k, v in self.scene.build_times().items()}
+        self.film = np.zeros((args.height, args.width, 3), np.int32)   # the caller's film buffer lives across frames (renderer.cuh:61)
+        return self.torch.zeros((args.height, args.width, 4), dtype=self.torch.float32, device=self.device)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def render_accum(self, accum, **opt):
+        a = self.args
+        kw = dict(spp=a.spp, spl=1, batch=a.spp + 1, tol=0.0, depth=a.depth)    # fixed spp: no adaptive stop
+        kw.update(opt)
+        return dict(self.scene.render_accum(a.width, a.height, accum.data_ptr(), **kw))
+
+    def tonemap(self, accum):
+        self.capi.tonemap(accum.data_ptr(), self.args.width, self.args.height, out=self.film)    # film in host memory
+
+    def report(self, opt, stats, rays, ms_per_step, world, accum):
+        return report(self, self.args, opt, stats, rays, ms_per_step, world, accum)
+
+    def cpu_baseline(self):
+        return cpu_baseline(self.sd, self.args)
 
 
 def traffic_table(args, world):
     """HBM bytes per launch of the three hot kernels, from the committed PMC passes of this same command (rocprofv3 cannot
     wrap itself: tools/make_profiles.sh collects FETCH_SIZE / WRITE_SIZE in separate runs and writes profiles/traffic.json
-    with the corrected figures).  {} when the file is absent or was collected on another configuration than the one running."""
+    with the corrected figures).  ({}, None) when the file is absent or was collected on another configuration."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             d = json.load(fh)
         mine = {"workload": args.workload, "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth,
                 "streams": args.streams, "traversal": args.traversal, "n_gpus": world}
         if d.get("configuration") != mine:
-            return {}
-        return {k: v["hbm_bytes_per_launch"] for k, v in d["kernels"].items()}
+            return {}, None
+        return {k: v["hbm_bytes_per_launch"] for k, v in d["kernels"].items()}, d.get("source")
     except (OSError, KeyError, ValueError, TypeError):
-        return {}
+        return {}, None
+
+
+def sq_table(args, world):
+    """Issue / lane / wait fractions of the hot kernels from the committed SQ counter passes (tools/pmc_run.sh on the bench
+    configuration -> profiles/r3_pmc_sq.csv -> tools/pmc_sq_json.py -> profiles/r3_pmc_sq.json).  None when absent or when
+    it was collected for another workload / traversal."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r3_pmc_sq.json")) as fh:
+            d = json.load(fh)
+        c = d.get("configuration", {})
+        if (c.get("workload"), c.get("traversal"), c.get("n_gpus")) != (args.workload, args.traversal, world):
+            return None
+        return d
+    except (OSError, ValueError, TypeError):
+        return None
 
 
 def cpu_baseline(scene_data, args):
@@ -118,44 +228,55 @@ def cpu_baseline(scene_data, args):
             "single_thread": {"value": one, "unit": "Mrays/s", "cores": 1, "sample": one_sample}}
 
 
-def main():
-    args = parse()
+def logic_bytes(st, K):
+    """Algorithmic bytes k_logic moves in the frame `st` describes, from what the frame actually did (SURVEY 8d's accounting,
+    16-byte records): a slot that runs the slot function reads and writes its state and running sum (64 B) and appends itself
+    to the live list (4 B); a slot a launch only looks at costs its state record (16 B); every extension ray is written
+    (origin, direction, path mask: 48 B + 4 B of queue) and, one iteration later, its hit read (16 B); every shaded hit reads
+    the ray, the mask, the primitive's normals and its material (32 + 16 + 48 + 48 B) -- shaded hits are counted as shadow
+    rays / K, exact for scenes without delta materials (conference*) and a lower bound otherwise -- and parks the mask for the
+    shadow fold (16 B written, 16 B read); every shadow ray is written (origin, direction, contribution: 48 B + 4 B of queue)
+    and its result read (4 + 16 B); every finished sample reads and writes the pixel's accumulator (32 B)."""
+    live, scanned = st["logic_live_slots"], st["logic_scanned_slots"]
+    ext, sh, paths = st["closest_rays"], st["shadow_rays"], st["paths"]
+    hits = sh / max(1, K)
+    return (live * (64 + 4) + (scanned - live) * 16 + ext * (48 + 4 + 16) + hits * (32 + 16 + 48 + 48 + 32)
+            + sh * (48 + 4 + 20) + paths * 32)
+
+
+def main(argv=None, backend_cls=GpuBackend, script=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks and does nothing else
+        raise SystemExit(launch_ranks(args.gpus, script or os.path.abspath(__file__), argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}: the two must agree")
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    if args.backend == "gloo":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+    be = backend_cls(args, rank, local_rank, world)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
-    coll_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
+        be.init_process_group(dist)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+    import torch
 
-    from raytracer_amd import capi, scenes
+    coll_dev = be.device if args.backend == "nccl" else "cpu"
 
     if args.streams == 0:
         spp_rank = args.spp // world if (world > 1 and args.partition == "spp") else args.spp
         args.streams = 8 if spp_rank >= 16 else 4
 
-    capi.init(local_rank)
-    sd, data_kind = scenes.workload(args.workload)             # objects/<name>.obj when present, else the stand-in of SURVEY 8(d)
-    sd.camera = sd.camera.for_aspect(args.width, args.height)
-    t0 = time.time()
-    scene = capi.Scene(sd, builder=args.builder)
-    build_s = time.time() - t0
-    build_ms = {k: round(v, 2) for k, v in scene.build_times().items()}
+    accum = be.setup()
     w, h = args.width, args.height
-    accum = torch.zeros((h, w, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
 
     # the timed steps carry HIP events around the dominant kernel's launches only (every event pair costs a little)
     opt = dict(rng_mode=args.rng, traversal=args.traversal, profile_closest=True, streams=args.streams if args.rng == 1 else 0,
@@ -164,25 +285,21 @@ def main():
 
     if world > 1 and args.partition == "spp" and args.spp < world:
         raise SystemExit("spp partition needs at least one sample per rank: use --partition tile")
-    kw = dict(spp=args.spp, spl=1, batch=args.spp + 1, tol=0.0, depth=args.depth)   # fixed spp: no adaptive stop
 
     def barrier():
-        torch.cuda.synchronize()
+        be.sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-
-    film = np.zeros((h, w, 3), np.int32)       # the caller's film buffer lives across frames, as the reference's sample_buffer does
+        be.sync()
 
     def step():
         # the one N > 1 code path (raytracer_amd/dist.py, rehearsed with gloo in tests/test_dist_cpu.py): partition options
         # for this rank -> libmirt -> ONE sum-reduce of the accumulation buffer onto rank 0
-        st = rdist.render_partitioned(lambda acc, **part: scene.render_accum(w, h, acc.data_ptr(), **kw, **{**opt, **part}),
-                                      accum, dist, rank, world, args.partition, args.spp, via_host=args.backend == "gloo")
-        if dist is not None:
-            torch.cuda.synchronize()
+        st = rdist.render_partitioned(lambda acc, **part: be.render_accum(acc, **{**opt, **part}),
+                                      accum, dist, rank, world, args.partition, args.spp, via_host=args.backend == "gloo",
+                                      sync=be.sync)
         if rank == 0:
-            capi.tonemap(accum.data_ptr(), w, h, out=film)          # film in host memory
+            be.tonemap(accum)
         return st
 
     for _ in range(args.warmup):
@@ -194,61 +311,25 @@ def main():
     elapsed = time.perf_counter() - t0
 
     rays = sum(s["closest_rays"] + s["shadow_rays"] for s in stats)
-    tl = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=coll_dev)
+    reduce_ms = sum(s.get("reduce_ms", 0.0) for s in stats) / max(1, args.steps)
+    n_ranks = world
+    tl = torch.tensor([elapsed, float(rays), reduce_ms], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         tmax = tl.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tl, op=dist.ReduceOp.SUM)
-        elapsed, rays = float(tmax[0]), float(tl[1])
+        elapsed, rays, reduce_ms = float(tmax[0]), float(tl[1]), float(tmax[2])
+        n_ranks = dist.get_world_size()                    # the ranks the collective library actually connected
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
 
     if rank == 0:
-        # traversal work per ray (counting build of the same kernels, one untimed reduced-spp frame)
-        cnt = scene.render_accum(w, h, accum.data_ptr(), spp=min(4, args.spp), spl=1, batch=args.spp + 1, tol=0.0,
-                                 depth=args.depth, **{**opt, "count": True, "sample_count": 0, "sample_begin": 0})
-        # one more untimed frame with events around EVERY launch: the per-kernel lines of the roofline (the timed steps carry
-        # events around the closest-hit launches only)
-        split = scene.render_accum(w, h, accum.data_ptr(), **kw, **{**opt, "profile": True, "profile_closest": False,
-                                                                  "sample_count": 0, "sample_begin": 0})
-        n_node = cnt["closest_node_visits"] / max(1, cnt["closest_rays"])
-        n_tri = cnt["closest_tri_tests"] / max(1, cnt["closest_rays"])
-        b_ray = B_STATE_CLOSEST + n_node * S_NODE[args.traversal] + n_tri * S_TRI
-        launches = sum(s["closest_launches"] for s in stats)
-        k_ms = sum(s["trace_closest_ms"] for s in stats)
-        k_rays = sum(s["closest_rays"] for s in stats)
-        avg_launch_ms = k_ms / max(1, launches)
-        achieved = (k_rays * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = traffic_table(args, world)
-        tname = "k_trace_fast" if args.traversal == 0 else "k_trace4" if args.traversal == 1 else "k_trace2"
-        # shadow rays: 96 B of state (ray write + read, contribution write + read) + their own traversal counts;
-        # k_logic per slot and iteration: state it reads (7 x 16 B + K x 20 B of shadow results + 48 B of normals + 48 B of
-        # material) and writes (6 x 16 B + K x 48 B of shadow rays + queue and live-list entries)
-        K = len(sd.lights) * 1
-        sn = cnt["shadow_node_visits"] / max(1, cnt["shadow_rays"])
-        st_ = cnt["shadow_tri_tests"] / max(1, cnt["shadow_rays"])
-        b_shadow = 96 + sn * S_NODE[args.traversal] + st_ * S_TRI
-        b_slot = (208 + 20 * K) + (96 + 48 * K) + (8 + 4 * K)
-        slots_per_launch = (w + 7) // 8 * ((h + 7) // 8) * 64 * max(1, opt["streams"]) / max(1, round(split["logic_launches"] / max(1, split["iterations"])))
-
-        def line(name, units, unit_name, b_unit, ms, n_launch):
-            ach = units * b_unit / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            t = traffic.get(name)
-            return {"kernel": name, "launches": n_launch, "avg_launch_ms": ms / max(1, n_launch), f"{unit_name}_per_launch": units / max(1, n_launch),
-                    f"bytes_per_{unit_name}": b_unit, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": t,
-                    "hbm_frac": None if t is None or ms <= 0 else t / (ms * 1e-3 / max(1, n_launch)) / 1e9 / HBM_PEAK_GBS}
-
-        per_kernel = [
-            line(f"{tname}<closest>", split["closest_rays"], "ray", b_ray, split["trace_closest_ms"], split["closest_launches"]),
-            line(f"{tname}<any>", split["shadow_rays"], "ray", b_shadow, split["trace_shadow_ms"], split["shadow_launches"]),
-            line("k_logic", slots_per_launch * split["logic_launches"], "slot", b_slot, split["logic_ms"], split["logic_launches"]),
-        ]
         out = {
             "metric": f"Mrays/s (all bounces), {args.workload.rstrip('*')}.obj stand-in {args.width}x{args.height} {args.spp}spp"
                       if (args.workload, args.width, args.height, args.spp) != ("conference*", 1920, 1080, 64)
                       else "Mrays/s (all bounces), conference.obj stand-in 1080p 64spp",
             "value": rays / elapsed / 1e6,
             "unit": "Mrays/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -257,34 +338,95 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "real (objects/%s.obj)" % args.workload.rstrip("*") if data_kind == "real"
-                    else "synthetic (procedural stand-in scene: the reference's .obj meshes are absent)",
-            "config": {"workload": f"{args.workload} {sd.n} tris, {w}x{h}, {args.spp} spp, depth {args.depth}, "
-                                   f"{len(sd.lights)} light{'s' if len(sd.lights) != 1 else ''}, rng {'counter' if opt['rng_mode'] else 'xorshift'}, "
-                                   f"traversal {args.traversal}, {opt['streams']} sample streams",
-                       "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
-                       "reference_walk_rays_per_frame": sum(s["exact_fallback_rays"] for s in stats) / max(1, args.steps),
-                       "scene_build_s": build_s, "builder": args.builder or "host", "build_ms": build_ms},
-            # the dominant kernel (closest-hit traversal) measured inside the timed steps; `kernels`: all three hot kernels in
-            # one extra frame with events around every launch.  `frac` = algorithmic bytes / time / HBM peak (the contract's
-            # figure); `hbm_frac` = measured HBM traffic (PMC) / time / HBM peak: what the kernel really asks of HBM - the
-            # traversal kernels are bound by the vector-L1 / L2 request rate of their divergent gathers, not by HBM
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get(f"{tname}<closest>"),
-                         "kernel": f"{tname}<closest>", "avg_launch_ms": avg_launch_ms, "launches": launches,
-                         "bytes_per_ray": b_ray, "node_visits_per_ray": n_node, "tri_tests_per_ray": n_tri,
-                         "kernel_rays_per_s": k_rays / (k_ms * 1e-3) if k_ms > 0 else 0.0,
-                         "closest_kernel_ms_timed_steps": k_ms,
-                         "hbm_frac": None if traffic.get(f"{tname}<closest>") is None or avg_launch_ms <= 0
-                         else traffic[f"{tname}<closest>"] / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "kernels": per_kernel},
         }
+        out.update(be.report(opt, stats, rays, ms_per_step, world, accum))      # data, config, roofline
+        if world > 1:
+            out["reduce_ms"] = reduce_ms                   # the frame's one collective, slowest rank, per step
+            out["config"]["backend"] = args.backend
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, args)
+            out["cpu_baseline"] = be.cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def report(be, args, opt, stats, rays, ms_per_step, world, accum):
+    """Rank 0, after the timed steps: `data`, `config` and `roofline` of the JSON line (two more untimed frames: a counting
+    build of the kernels, and one with events around every launch)."""
+    scene, sd = be.scene, be.sd
+    w, h = args.width, args.height
+    # traversal work per ray (counting build of the same kernels, one untimed reduced-spp frame)
+    cnt = be.render_accum(accum, **{**opt, "spp": min(4, args.spp), "batch": args.spp + 1, "count": True, "sample_count": 0,
+                                    "sample_begin": 0})
+    # one more untimed frame with events around EVERY launch: the per-kernel lines of the roofline (the timed steps carry
+    # events around the closest-hit launches only)
+    split = be.render_accum(accum, **{**opt, "profile": True, "profile_closest": False, "sample_count": 0, "sample_begin": 0})
+    n_node = cnt["closest_node_visits"] / max(1, cnt["closest_rays"])
+    n_tri = cnt["closest_tri_tests"] / max(1, cnt["closest_rays"])
+    b_ray = B_STATE_CLOSEST + n_node * S_NODE[args.traversal] + n_tri * S_TRI
+    launches = sum(s["closest_launches"] for s in stats)
+    k_ms = sum(s["trace_closest_ms"] for s in stats)
+    k_rays = sum(s["closest_rays"] for s in stats)
+    avg_launch_ms = k_ms / max(1, launches)
+    achieved = (k_rays * b_ray) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic, traffic_src = traffic_table(args, world)
+    tname = "k_trace_fast" if args.traversal == 0 else "k_trace4" if args.traversal == 1 else "k_trace2"
+    # shadow rays: 96 B of state (ray write + read, contribution write + read) + their own traversal counts
+    K = len(sd.lights) * 1
+    sn = cnt["shadow_node_visits"] / max(1, cnt["shadow_rays"])
+    st_ = cnt["shadow_tri_tests"] / max(1, cnt["shadow_rays"])
+    b_shadow = 96 + sn * S_NODE[args.traversal] + st_ * S_TRI
+    # k_logic: bytes of the slots that actually ran (logic_bytes), not a full slot record for every slot of every launch
+    lb = logic_bytes(split, K)
+    live = split["logic_live_slots"]
+
+    def line(name, units, unit_name, total_bytes, ms, n_launch):
+        ach = total_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        t = traffic.get(name)
+        return {"kernel": name, "launches": n_launch, "avg_launch_ms": ms / max(1, n_launch), f"{unit_name}_per_launch": units / max(1, n_launch),
+                f"bytes_per_{unit_name}": total_bytes / max(1, units), "algorithmic_bytes_per_frame": total_bytes,
+                "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": t,
+                "hbm_frac": None if t is None or ms <= 0 else t / (ms * 1e-3 / max(1, n_launch)) / 1e9 / HBM_PEAK_GBS}
+
+    per_kernel = [
+        line(f"{tname}<closest>", split["closest_rays"], "ray", split["closest_rays"] * b_ray, split["trace_closest_ms"], split["closest_launches"]),
+        line(f"{tname}<any>", split["shadow_rays"], "ray", split["shadow_rays"] * b_shadow, split["trace_shadow_ms"], split["shadow_launches"]),
+        line("k_logic", live, "live_slot", lb, split["logic_ms"], split["logic_launches"]),
+    ]
+    per_kernel[2]["scanned_slots_per_launch"] = split["logic_scanned_slots"] / max(1, split["logic_launches"])
+    # whole frame: the kernels overlap, so the per-kernel `frac`s are rates while each kernel runs, not shares of one HBM;
+    # what one HBM has to carry per frame is the sum below, over the frame time
+    frame_alg = sum(k["algorithmic_bytes_per_frame"] for k in per_kernel)
+    frame = {"algorithmic_bytes": frame_alg, "algorithmic_frac": frame_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "hbm_bytes": None, "hbm_frac": None, "source": traffic_src}
+    if traffic and all(k["traffic"] is not None for k in per_kernel):
+        hb = sum(k["traffic"] * k["launches"] for k in per_kernel)
+        frame["hbm_bytes"] = hb
+        frame["hbm_frac"] = hb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return {
+        "data": "real (objects/%s.obj)" % args.workload.rstrip("*") if be.data_kind == "real"
+                else "synthetic (procedural stand-in scene: the reference's .obj meshes are absent)",
+        "config": {"workload": f"{args.workload} {sd.n} tris, {w}x{h}, {args.spp} spp, depth {args.depth}, "
+                               f"{len(sd.lights)} light{'s' if len(sd.lights) != 1 else ''}, rng {'counter' if opt['rng_mode'] else 'xorshift'}, "
+                               f"traversal {args.traversal}, {opt['streams']} sample streams",
+                   "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
+                   "reference_walk_rays_per_frame": sum(s["exact_fallback_rays"] for s in stats) / max(1, args.steps),
+                   "scene_build_s": be.build_s, "builder": args.builder or "host", "build_ms": be.build_ms},
+        # the dominant kernel (closest-hit traversal) measured inside the timed steps; `kernels`: all three hot kernels in
+        # one extra frame with events around every launch.  `frac` = algorithmic bytes / time / HBM peak (the contract's
+        # figure); `hbm_frac` = measured HBM traffic (PMC) / time / HBM peak: what the kernel really asks of HBM - the
+        # traversal kernels are bound by dependent-fetch latency under divergence, not by HBM (`sq`, DESIGN.md 5)
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic.get(f"{tname}<closest>"),
+                     "kernel": f"{tname}<closest>", "avg_launch_ms": avg_launch_ms, "launches": launches,
+                     "bytes_per_ray": b_ray, "node_visits_per_ray": n_node, "tri_tests_per_ray": n_tri,
+                     "kernel_rays_per_s": k_rays / (k_ms * 1e-3) if k_ms > 0 else 0.0,
+                     "closest_kernel_ms_timed_steps": k_ms,
+                     "hbm_frac": None if traffic.get(f"{tname}<closest>") is None or avg_launch_ms <= 0
+                     else traffic[f"{tname}<closest>"] / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "kernels": per_kernel, "frame": frame, "sq": sq_table(args, world)},
+    }
 
 
 if __name__ == "__main__":

@@ -71,11 +71,16 @@ typedef struct mirt_options {
   uint32_t rng_mode;        /* 0 = reference xorshift32 stream per pixel (util/sampler.cuh:8-15, renderer.cuh:50-51);
                                1 = counter-based Philox2x32-10 keyed by (pixel, sample, seed): needed for spp slices */
   uint32_t seed;            /* rng_mode 0: xor-ed into the pixel seed (0 = the reference); rng_mode 1: global seed */
-  uint32_t traversal;       /* 0 = ordered traversal of the library's own 8-wide SAH tree; rays whose outcome could hinge on
-                                   the reference's own box tests are re-traced by the reference walk, so results equal the
-                                   reference's
-                               1 = the reference's tree folded to 4-wide nodes, visited in the reference's DFS order
-                                   (bit-exact with bvh.cuh:78-107 by construction)
+  uint32_t traversal;       /* 0 = ordered traversal of the library's own 8-wide SAH tree (default, fastest); rays whose
+                                   outcome could hinge on the reference's own box tests are re-traced by the reference walk.
+                                   Equal to the reference on every fixture, test and soak EXCEPT one known class of rays
+                                   ("what remains open"): a ray within ~0.05 degrees of a triangle's plane for
+                                   which the reference accepts an ill-conditioned Moeller-Trumbore hit lying in front of that
+                                   triangle's own box.  Measured: 2 of 72 M aimed queries, 0 of 600 M arbitrary ones; the
+                                   ray is pinned in tests/test_gpu_configs.py::test_known_counter_example_of_traversal_0.
+                               1 = the reference's tree folded to 4-wide nodes, visited in the reference's DFS order:
+                                   THE PROVABLY EXACT MODE (bit-exact with bvh.cuh:78-107 by construction); its frame cost
+                                   next to mode 0 is tabulated in DESIGN.md 5
                                2 = the reference's BVH2 walked as the reference does (cross-check) */
   uint32_t tile_rank;       /* tile partition: this process renders 8x8 tiles t with t % tile_world == tile_rank */
   uint32_t tile_world;      /* 0 or 1 = whole image */
@@ -117,6 +122,10 @@ typedef struct mirt_stats {
    * (non-finite vertex coordinates) */
   uint32_t traversal_used;
   uint32_t logic_launches;  /* launches of k_logic behind logic_ms (flags bit 0) */
+  /* k_logic's work over the frame, from the queue counters the host reads anyway: slots that ran the slot function (still
+   * rendering at the launch) and slots a launch looked at (all of a pipe's slots, or its live-slot list in the frame's tail).
+   * What bench.py prices k_logic's algorithmic bytes with. */
+  uint64_t logic_live_slots, logic_scanned_slots;
 } mirt_stats;
 
 typedef struct mirt_scene mirt_scene;

@@ -65,7 +65,8 @@ class Stats(C.Structure):
                 ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
                 ("closest_node_steps", C.c_uint64), ("closest_tri_steps", C.c_uint64),
                 ("shadow_node_steps", C.c_uint64), ("shadow_tri_steps", C.c_uint64),
-                ("traversal_used", C.c_uint32), ("logic_launches", C.c_uint32)]
+                ("traversal_used", C.c_uint32), ("logic_launches", C.c_uint32),
+                ("logic_live_slots", C.c_uint64), ("logic_scanned_slots", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

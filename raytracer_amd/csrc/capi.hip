@@ -888,7 +888,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     }
   }
   uint32_t iters = 0;
-  uint64_t n_camera = 0, n_bounced = 0, n_shadow_rays = 0;
+  uint64_t n_camera = 0, n_bounced = 0, n_shadow_rays = 0, n_live = 0, n_scanned = 0;
   if (part.n_slots) {
     if (n_pipes >= 2) {                                                  // the other pipes start after the clears above
       HIPCHK(hipEventRecord(G.pipe_ev[0], G.stream));
@@ -977,7 +977,14 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
             __builtin_ia32_pause();
           }
           std::atomic_thread_fence(std::memory_order_acquire);
-          const uint32_t c_front = hc[0], c_back = hc[1], c_shadow = hc[2], c_culled = hc[4];   // QC_* / CTR_STRIDE
+          const uint32_t c_front = hc[0], c_back = hc[1], c_shadow = hc[2], c_live = hc[3], c_culled = hc[4];   // QC_* / CTR_STRIDE
+          // k_logic's work: iteration 0 runs every slot; iteration i + 1 runs the slots iteration i left rendering, and looks
+          // at all of the pipe's slots unless the live-slot list is short enough (the rule of k_logic itself)
+          if (old == 0) { n_live += pp.a.n_slots; n_scanned += pp.a.n_slots; }
+          if (c_front + c_back + c_shadow != 0) {
+            n_live += c_live;
+            n_scanned += ((uint64_t) c_live * 16u <= (uint64_t) pp.a.n_slots * G.live_16th) ? c_live : pp.a.n_slots;
+          }
           // a slot that is not finished leaves a ray in one of the queues: empty queues = this half is complete (and
           // every later iteration already launched found them empty too)
           n_camera += c_front;
@@ -1042,6 +1049,8 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     stats->shadow_tri_steps = rs[11];
     stats->traversal_used = o.traversal;
     stats->logic_launches = n_kind[0];
+    stats->logic_live_slots = n_live;
+    stats->logic_scanned_slots = n_scanned;
     stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   }
   return MIRT_OK;

@@ -61,11 +61,20 @@ def reduce_accum(accum, dist, dst=0, via_host=False):
     return accum
 
 
-def render_partitioned(render_accum, accum, dist, rank, world, kind, spp, via_host=False):
+def render_partitioned(render_accum, accum, dist, rank, world, kind, spp, via_host=False, sync=None):
     """One frame over `world` ranks -- the N > 1 path of bench.py and of tests/test_dist_cpu.py: this rank renders its
     partition into `accum` (`render_accum(accum, **partition_options)` -> stats; pixels / samples it does not own contribute
-    zeros), then the buffers are summed onto rank 0.  Returns the rank's stats."""
+    zeros), then the buffers are summed onto rank 0.  Returns the rank's stats; with N > 1 they carry `reduce_ms`, this
+    rank's wall time in the collective (`sync`: waits for the device, e.g. torch.cuda.synchronize -- the RCCL reduce is
+    asynchronous to the host; the wait also covers ranks that arrive late, so it is an upper bound of the transfer)."""
     stats = render_accum(accum, **partition_options(kind, rank, world, spp))
     if world > 1:
+        import time
+
+        t0 = time.perf_counter()
         reduce_accum(accum, dist, dst=0, via_host=via_host)
+        if sync is not None:
+            sync()
+        stats = dict(stats)
+        stats["reduce_ms"] = 1e3 * (time.perf_counter() - t0)
     return stats

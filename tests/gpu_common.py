@@ -61,3 +61,44 @@ def aimed_rays(sc, n, seed):
     r[:, 6] = 1e-5
     r[:, 7] = np.inf
     return r
+
+
+def grazing_rays(sc, n, seed):
+    """Rays that run almost IN the plane of a triangle (1e-6 ... 1e-2 rad off it) through a point of that triangle: the regime
+    in which Moeller-Trumbore is ill-conditioned (|det| = 2 area |cos incidence| -> 0) and reports hits from outside the
+    triangle, at distances that can lie in front of the triangle's own box -- the one class of rays on which the ordered
+    traversal is known to differ from the reference (DESIGN.md 4).  Targets: interior points, edge midpoints and vertices;
+    near and far origins; float32 arithmetic, unit directions."""
+    rng = np.random.default_rng(seed)
+    tri = sc.pos.reshape(-1, 3, 3).astype(np.float64)
+    if sc.ptype is not None:
+        tri = tri[sc.ptype == 2]
+    pick = rng.integers(0, len(tri), n)
+    a, b, c = tri[pick, 0], tri[pick, 1], tri[pick, 2]
+    kind = rng.integers(0, 3, n)                       # 0 interior point, 1 edge midpoint, 2 vertex
+    u, v = rng.uniform(0, 1, n), rng.uniform(0, 1, n)
+    flip = u + v > 1
+    u, v = np.where(flip, 1 - u, u), np.where(flip, 1 - v, v)
+    tgt = a + u[:, None] * (b - a) + v[:, None] * (c - a)
+    tgt = np.where((kind == 1)[:, None], 0.5 * (a + b), tgt)
+    tgt = np.where((kind == 2)[:, None], a, tgt)
+    nrm = np.cross(b - a, c - a)
+    nl = np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm = nrm / np.where(nl > 0, nl, 1)
+    g = rng.normal(size=(n, 3))
+    inplane = g - (g * nrm).sum(1, keepdims=True) * nrm
+    inplane /= np.maximum(np.linalg.norm(inplane, axis=1, keepdims=True), 1e-30)
+    eps = 10.0 ** rng.uniform(-6, -2, n) * rng.choice([-1, 1], n)
+    d = inplane + eps[:, None] * nrm
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dist = np.where(rng.integers(0, 2, n) == 1, rng.uniform(5, 40, n), rng.uniform(0.3, 3, n))[:, None]
+    org = (tgt - d * dist).astype(np.float32)
+    d32 = (tgt.astype(np.float32) - org).astype(np.float32)
+    ln = np.sqrt((d32 * d32).sum(1, dtype=np.float32), dtype=np.float32)[:, None]
+    d32 = (d32 / ln).astype(np.float32)
+    r = np.zeros((n, 8), np.float32)
+    r[:, :3] = org
+    r[:, 3:6] = d32
+    r[:, 6] = 1e-5
+    r[:, 7] = np.inf
+    return r

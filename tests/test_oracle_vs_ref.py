@@ -71,3 +71,16 @@ def test_multithreaded_ref_equals_serial(ref):
     sc = scenes.cornell_scene(1, "diffuse")
     ref.load(sc)
     assert (ref.render(40, 30, spp=4, depth=3, nthreads=1) == ref.render(40, 30, spp=4, depth=3, nthreads=4)).all()
+
+
+def test_known_counter_example_ray_of_traversal_0(oracle, ref):
+    """The ray pinned in tests/test_gpu_configs.py (COUNTER_EXAMPLE_RAY): the reference itself returns prim 25 at t = 39.67084,
+    an ill-conditioned Moeller-Trumbore hit in front of that triangle's own box; the oracle agrees bitwise."""
+    from test_gpu_configs import COUNTER_EXAMPLE_RAY, COUNTER_EXAMPLE_REF, _open_meshes
+
+    sc = _open_meshes()["cut"]
+    ray = np.array([COUNTER_EXAMPLE_RAY], np.float32)
+    for tr in (oracle, ref):
+        tr.load(sc)
+        i, t = tr.trace(ray)
+        assert (int(i[0]), int(t[0])) == COUNTER_EXAMPLE_REF
