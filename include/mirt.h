@@ -11,8 +11,9 @@
  *     (the reference prints and returns / exit(1)s: renderer.cuh:118-133, util/misc.cuh:33-43);
  *   - host pointers are caller-owned and only touched during the call; device memory lives behind mirt_scene;
  *   - the library context (streams, events, pinned memory) belongs to the host thread that called mirt_init; one render in
- *     flight per host thread (the reference is single-threaded and blocking too, renderer.cuh:178); a scene is used from
- *     the thread that created it.
+ *     flight per host thread (the reference is single-threaded and blocking too, renderer.cuh:178).  A scene belongs to the
+ *     DEVICE it was created on: using it from a thread whose context is on another device (or after mirt_init moved this
+ *     thread to another device) fails with MIRT_E_STATE; another thread on the same device may use it (one call at a time).
  *   - the GPU is mandatory: there is no CPU fallback; without a usable HIP device every compute entry point fails with
  *     MIRT_E_DEVICE.
  */
@@ -73,11 +74,14 @@ typedef struct mirt_options {
   uint32_t seed;            /* rng_mode 0: xor-ed into the pixel seed (0 = the reference); rng_mode 1: global seed */
   uint32_t traversal;       /* 0 = ordered traversal of the library's own 8-wide SAH tree (default, fastest); rays whose
                                    outcome could hinge on the reference's own box tests are re-traced by the reference walk.
-                                   Equal to the reference on every fixture, test and soak EXCEPT one known class of rays
-                                   ("what remains open"): a ray within ~0.05 degrees of a triangle's plane for
-                                   which the reference accepts an ill-conditioned Moeller-Trumbore hit lying in front of that
-                                   triangle's own box.  Measured: 2 of 72 M aimed queries, 0 of 600 M arbitrary ones; the
-                                   ray is pinned in tests/test_gpu_configs.py::test_known_counter_example_of_traversal_0.
+                                   Equal to the reference on every fixture and on every soak of arbitrary rays (0 of 600 M),
+                                   EXCEPT one known class ("what remains open"): a ray that runs almost in the
+                                   plane of a triangle, for which the reference accepts an ill-conditioned Moeller-Trumbore
+                                   "hit" lying in front of that triangle's own box and of the true nearest hit; an ordered
+                                   traversal has pruned that box by distance.  Measured: 1 of 36 M rays aimed at vertices and
+                                   edges; 1 - 6 per 10 000 rays CONSTRUCTED to run 1e-6 ... 1e-2 rad off a triangle's plane
+                                   (profiles/r3_grazing_soak.txt).  Pinned: tests/test_gpu_configs.py
+                                   ::test_known_counter_example_of_traversal_0, ::test_grazing_rays_exact_modes_and_rate_...
                                1 = the reference's tree folded to 4-wide nodes, visited in the reference's DFS order:
                                    THE PROVABLY EXACT MODE (bit-exact with bvh.cuh:78-107 by construction); its frame cost
                                    next to mode 0 is tabulated in DESIGN.md 5
@@ -230,7 +234,8 @@ int mirt_trace(mirt_scene *scene, const float *rays, uint32_t n, int any_hit, ui
 
 /* mirt_trace without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot call hipMalloc --
  * code under HIP graph capture, tight serving loops, harnesses that forbid it.  rays_dev (n x 8 floats, as mirt_trace),
- * idx_dev and tbits_dev (n each) are DEVICE memory of the caller; results as mirt_trace (no barycentrics).  Every
+ * idx_dev and tbits_dev (n each) are DEVICE memory of the caller; results as mirt_trace (no barycentrics).  rays_dev must be
+ * 16-byte aligned (the records are read as float4), idx_dev / tbits_dev 4-byte aligned: MIRT_E_ARG otherwise.  Every
  * intermediate (ray and hit records, queues, counters, the traversal's stack overflow region) lives in one static device
  * array of ~10 MB that each GPU the library runs on holds until the process ends; its address is looked up once per
  * device in mirt_init.  Limit, rejected with MIRT_E_LIMIT: n <= MIRT_TRACE_STATIC_MAX_RAYS (a ray whose traversal stack

@@ -21,32 +21,18 @@
 #ifndef uint
 #define uint unsigned int
 #endif
+// util/misc.cuh:10-19: the constants an application can name (apps/app.cu passes INF_F as the far clip)
+#ifndef PI
+#define PI 3.14159265358979323f
+#endif
+#ifndef EPS_F
+#define EPS_F 0.00001f
+#endif
+#ifndef INF_F
+#define INF_F INFINITY
+#endif
 
-struct Vector3f {
-  float x = 0, y = 0, z = 0;
-  Vector3f() = default;
-  Vector3f(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {}
-  Vector3f operator*(const Vector3f &v) const { return {x * v.x, y * v.y, z * v.z}; }
-  Vector3f operator+(const Vector3f &v) const { return {x + v.x, y + v.y, z + v.z}; }
-  Vector3f operator-(const Vector3f &v) const { return {x - v.x, y - v.y, z - v.z}; }
-  Vector3f operator-() const { return {-x, -y, -z}; }
-  void operator+=(const Vector3f &v) { x += v.x; y += v.y; z += v.z; }
-  Vector3f operator*(float c) const { return {x * c, y * c, z * c}; }
-  Vector3f operator/(float c) const {                       // linalg/Vector3f.cuh:106-109: reciprocal in double, three multiplies
-    float rc = (float) (1.0 / (double) c);
-    return {x * rc, y * rc, z * rc};
-  }
-  Vector3f cross(const Vector3f &v) const { return {y * v.z - z * v.y, z * v.x - x * v.z, x * v.y - y * v.x}; }
-  float norm() const { return (float) std::sqrt((double) (x * x + y * y + z * z)); }
-  Vector3f unit() const {                                   // linalg/Vector3f.cuh:161-164
-    float r = (float) (1. / (double) norm());
-    return {x * r, y * r, z * r};
-  }
-};
-
-struct Vector3i {
-  int x = 0, y = 0, z = 0;
-};
+#include "linalg.hpp"      // Vector3f / Vector2f / Vector3i / Matrix3f of the kept API (linalg/*.cuh)
 
 // scene/bsdf.cuh:31-67 -- the stored record IS the C-ABI record
 class BSDF {
@@ -80,15 +66,30 @@ public:
   }
 };
 
-// the presets the reference's from_obj refers to (scene/bsdf.cuh:358-388)
+// the 19 presets of scene/bsdf.cuh:358-388, same names.  The conductors are measured optical constants (eta, k per RGB
+// channel): data, restated as a table.
 static BSDF mirror_bsdf = BSDFFactory::createReflection(0.f, {.9f, .9f, .9f});
+static BSDF refract_bsdf = BSDFFactory::createRefraction(1.45f, 0.f, {1, 1, 1});
+static BSDF glass_bsdf = BSDFFactory::createGlass(1.45f, 0.f, {1, 1, 1}, {1, 1, 1});
+#define MIRT_CONDUCTOR(name, alpha, er, eg, eb, kr, kg, kb) \
+  static BSDF name##_bsdf = BSDFFactory::createMicrofacet((float) (alpha), {(float) (er), (float) (eg), (float) (eb)}, {(float) (kr), (float) (kg), (float) (kb)})
+MIRT_CONDUCTOR(aluminum, 0.5, 1.34560, 0.96521, 0.61722, 7.47460, 6.39950, 5.30310);
+MIRT_CONDUCTOR(brass, 0.5, 0.44400, 0.52700, 1.09400, 3.69500, 2.76500, 1.82900);
+MIRT_CONDUCTOR(copper, 0.5, 0.27105, 0.67693, 1.31640, 3.60920, 2.62480, 2.29210);
+MIRT_CONDUCTOR(gold, 0.05, 0.18299, 0.42108, 1.37340, 3.42420, 2.34590, 1.77040);
+MIRT_CONDUCTOR(iron, 0.5, 2.91140, 2.94970, 2.58450, 3.08930, 2.93180, 2.76700);
+MIRT_CONDUCTOR(lead, 0.5, 1.91000, 1.83000, 1.44000, 3.51000, 3.40000, 3.18000);
+MIRT_CONDUCTOR(mercury, 0.5, 2.07330, 1.55230, 1.06060, 5.33830, 4.65100, 3.86280);
+MIRT_CONDUCTOR(platinum, 0.5, 2.37570, 2.08470, 1.84530, 4.26550, 3.71530, 3.13650);
+MIRT_CONDUCTOR(silver, 0.5, 0.15943, 0.14512, 0.13547, 3.92910, 3.19000, 2.38080);
+MIRT_CONDUCTOR(titanium, 0.5, 2.74070, 2.54180, 2.26700, 3.81430, 3.43450, 3.03850);
+MIRT_CONDUCTOR(blue_metal, 0.5, 2.5, .2, .05, 0.5, 0.5, 0.5);
+#undef MIRT_CONDUCTOR
+static BSDF black_bsdf = BSDFFactory::createDiffuse({0, 0, 0});
 static BSDF white_bsdf = BSDFFactory::createDiffuse({.6f, .6f, .6f});
 static BSDF red_bsdf = BSDFFactory::createDiffuse({.6f, .2f, .2f});
 static BSDF green_bsdf = BSDFFactory::createDiffuse({.2f, .6f, .2f});
 static BSDF blue_bsdf = BSDFFactory::createDiffuse({.2f, .2f, .6f});
-static BSDF black_bsdf = BSDFFactory::createDiffuse({0, 0, 0});
-static BSDF glass_bsdf = BSDFFactory::createGlass(1.45f, 0.f, {1, 1, 1}, {1, 1, 1});
-static BSDF refract_bsdf = BSDFFactory::createRefraction(1.45f, 0.f, {1, 1, 1});
 
 struct Primitive {                                           // scene/primitives.cuh:10-27
   enum { INVALID, SPHERE, TRIANGLE } type = INVALID;

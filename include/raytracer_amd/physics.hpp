@@ -88,15 +88,15 @@ public:
 
   BSDF *new_bsdf() const { return new BSDF(BSDFFactory::createEmission(kelvinToRGB(temp))); }
 
-  Vector3f get_drag() const {                                // DRAG_COEF 0.45 * r^2 * v * |v|, in double as the macros make it
-    const double c = 0.45 * pow((double) radius, 2);
-    Vector3f d = {(float) (c * velocity.x), (float) (c * velocity.y), (float) (c * velocity.z)};
-    return d * velocity.norm();
+  // The reference's Vector3f has only FLOAT scalar operators (Vector3f.cuh:101, :106, :180), so the double-typed factors of
+  // these expressions - DRAG_COEF * pow(radius, 2), GRAVITY_ACCEL, pow(dt, 2) - are rounded to float where they meet a vector
+  // and the products are formed in float, left to right.  The same expressions here, with those conversions spelled out.
+  Vector3f get_drag() const {                                // particle.cuh:60-63
+    const float c = (float) (0.45 * pow((double) radius, 2));
+    return c * velocity * velocity.norm();
   }
-  Vector3f get_forces(float) const {
-    const double g = -9.8;                                   // GRAVITY_ACCEL
-    Vector3f w = {0, (float) ((double) 1.0f * g), 0};
-    return w * mass - get_drag();
+  Vector3f get_forces(float) const {                         // particle.cuh:65-67
+    return Vector3f(0, 1, 0) * (float) -9.8 * mass - get_drag();
   }
   void clamp_position() {
     if (position.y < 0) {
@@ -106,10 +106,8 @@ public:
   }
   void clamp_temperature() { temp = temp < 100.f ? 100.f : temp; }   // maxf(temp, 100), see the header comment
   void step_position(float dt) {
-    Vector3f acceleration = get_forces(dt) / mass;
-    const double h = pow((double) dt, 2);
-    Vector3f q = {(float) ((double) acceleration.x * h), (float) ((double) acceleration.y * h), (float) ((double) acceleration.z * h)};
-    position += velocity * dt + q / 2;
+    Vector3f acceleration = get_forces(dt) / mass;           // particle.cuh:80-86
+    position += velocity * dt + acceleration * (float) pow((double) dt, 2) / 2;
     velocity += acceleration * dt;
     clamp_position();
   }

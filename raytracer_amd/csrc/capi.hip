@@ -170,6 +170,7 @@ struct mirt_scene {
   DevBuf nodes4, nodes2, tris, tri_nrm, mats, lights, big, trisf, nodes8q, verts;
   uint32_t ovf_depth = 0;
   uint32_t trace_threads = 0;
+  int device = -1;                       // the HIP device its buffers live on (the creating thread's context)
   // work buffers (sized per render)
   DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2], mf_queue, live[2];
   DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t, planes;
@@ -371,6 +372,7 @@ static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const u
     g_building = nullptr;
     return fail(MIRT_E_LIMIT, "reference BVH deeper than the traversal stack (62 levels)");
   }
+  s->device = G.device;
   s->n_tris = n_tris;
   s->n_mats = n_mats;
   s->n_lights = n_lights;
@@ -636,7 +638,20 @@ Partition make_partition(uint32_t w, uint32_t h, const mirt_options &o) {
   return p;
 }
 
+// The traversal-stack overflow regions live in the library context of the CALLING thread (Global::ovf), a scene's ovf_depth and
+// trace_threads are fixed when it is created: a scene used from another host thread's context, or after mirt_init() moved this
+// thread to another device (which releases the context's buffers), must not find a missing or smaller buffer - the kernels
+// index it unchecked.  Called by every entry point that launches a traversal with G.ovf.
+int ensure_overflow_region(const mirt_scene *s) {
+  if (s->device != G.device)
+    return fail(MIRT_E_STATE, "the scene was created on device " + std::to_string(s->device) + ", this thread's context is on device " +
+                                  std::to_string(G.device) + " (mirt_init): a scene is used on the device it was created on");
+  HIPCHK(G.ovf.ensure(2 * MAX_PIPES * (size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)));
+  return MIRT_OK;
+}
+
 int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
+  if (int rc = ensure_overflow_region(s)) return rc;
   const size_t n = n_slots ? n_slots : 64, kn = (size_t) (K ? K : 1) * n;
   HIPCHK(s->st.ensure(n * 16));
   HIPCHK(s->mask.ensure(n * 16));
@@ -743,7 +758,11 @@ int run_trace(mirt_scene *s, TraceArgs t, bool any, uint32_t traversal, std::vec
     HIPCHK(hipEventRecord(tm.b, stream));
     timed->push_back(tm);
   }
-  static const int skip_redo = getenv("MIRT_SKIP_REDO") ? atoi(getenv("MIRT_SKIP_REDO")) : 0;   // timing experiments only: WRONG results
+#ifdef MIRT_TIMING_EXPERIMENTS                               // tools/redo_bound.sh builds a variant with it: WRONG results, timing only
+  static const int skip_redo = getenv("MIRT_SKIP_REDO") ? atoi(getenv("MIRT_SKIP_REDO")) : 0;
+#else
+  constexpr int skip_redo = 0;                               // the shipped library always runs the reference walk
+#endif
   if (traversal != 2 && !((skip_redo & 1) && any) && !((skip_redo & 2) && !any)) {
     t.redo = 1;
     HIPCHK(launch_trace(t, any, 2, 256, stream));
@@ -1250,8 +1269,11 @@ int mirt_trace_static(mirt_scene *s, const float *rays_dev, uint32_t n, int any_
   if (traversal == 0 && !s->fast_ok) traversal = 1;
   unsigned char *base = (G.device >= 0 && G.device < MAX_DEVICES) ? g_scratch_ptr[G.device] : nullptr;
   if (!base) return fail(MIRT_E_STATE, "mirt_trace_static: no scratch address for this device");
+  if (s->device != G.device) return fail(MIRT_E_STATE, "mirt_trace_static: the scene lives on another device than this thread's context");
   if (n == 0) return MIRT_OK;
   if (!rays_dev) return fail(MIRT_E_ARG, "rays_dev is null");
+  if (((uintptr_t) rays_dev & 15u) || ((uintptr_t) idx_dev & 3u) || ((uintptr_t) tbits_dev & 3u))
+    return fail(MIRT_E_ARG, "mirt_trace_static: rays_dev must be 16-byte aligned (it is read as float4), idx_dev / tbits_dev 4-byte aligned");
   uint32_t *ctrl = (uint32_t *) (base + SO_CTRL);
   TraceArgs t = common_args(s, traversal);
   t.ray_o = (const float4 *) (base + SO_RAY_O);

@@ -14,6 +14,27 @@ SCENES = {
 SPHERE_SCENES = {"sphere_soup": lambda: scenes.sphere_soup(300, 60, 3), "known_answer": scenes.known_answer_scene}
 
 
+def film_delta(name, img, want, log="gpurun_out/r3_film_delta.txt"):
+    """How a film differs from the reference's: fraction of differing bytes, how many of them are off by exactly one level
+    (the device libm's sinf / cosf / acosf round the last ulp differently: a radiance an ulp away lands on the other side of
+    a tonemap threshold), how many by more (a bounce direction an ulp away crossed a silhouette: another path, any delta), the
+    largest delta.  Appends one line per call to `log` (copied to profiles/ by hand) and returns the numbers."""
+    import os
+
+    d = np.abs(np.asarray(img, np.int64) - np.asarray(want, np.int64))
+    n = d.size
+    st = {"bytes": n, "differ": int((d > 0).sum()), "by_one": int((d == 1).sum()), "by_more": int((d > 1).sum()), "max": int(d.max()),
+          "pixels_by_more": int((d.reshape(-1, 3) > 1).any(1).sum())}
+    try:
+        os.makedirs(os.path.dirname(log), exist_ok=True)
+        with open(log, "a") as fh:
+            fh.write(f"{name:44s} {n:9d} bytes: {st['differ']:6d} differ ({st['differ'] / n:.2e}), {st['by_one']:6d} by one level, "
+                     f"{st['by_more']:5d} by more ({st['by_more'] / n:.2e}; {st['pixels_by_more']} pixels), max {st['max']}\n")
+    except OSError:
+        pass
+    return st
+
+
 def random_rays(sc, n, seed, unit):
     rng = np.random.default_rng(seed)
     lo = sc.pos.reshape(-1, 3).min(0) - 0.5

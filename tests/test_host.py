@@ -192,3 +192,53 @@ def test_threaded_builders_do_not_depend_on_the_thread_count(monkeypatch):
     for b in out[1:]:
         for key in ("nodes2", "flat", "nodes4", "nodes8q", "fast_to_flat"):
             assert (b[key] == out[0][key]).all(), key
+
+
+# ---- the kept host API's math types and presets (include/raytracer_amd/linalg.hpp, pathtracer.hpp, physics.hpp)
+def _gxx(args, **kw):
+    import subprocess
+
+    return subprocess.run(["g++", "-std=c++17", "-ffp-contract=off", "-w", "-I", os.path.join(ROOT, "include")] + args,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, **kw)
+
+
+@pytest.mark.parametrize("with_particle", [False, True])
+def test_linalg_mirror_equals_the_references_types_bitwise(tmp_path, with_particle):
+    """oracle/linalg_probe.cpp built against the mirror's Vector3f / Vector2f / Matrix3f prints the same bit patterns as the
+    build against the reference's own headers (tests/golden/linalg_probe.txt, written by oracle/Makefile): every operator, and
+    40 steps of the particle demo's update for 50 particles - with_particle: through physics.hpp's Particle::step, whose
+    reference counterpart cannot be compiled under g++ (particle.cuh:77), so its expressions are what the golden holds."""
+    exe = str(tmp_path / "probe")
+    r = _gxx(["-O2"] + (["-DWITH_PARTICLE"] if with_particle else []) + ["-o", exe, os.path.join(ROOT, "oracle", "linalg_probe.cpp")])
+    assert r.returncode == 0, r.stderr[-2000:]
+    import subprocess
+
+    got = subprocess.run([exe], stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+    want = open(os.path.join(ROOT, "tests", "golden", "linalg_probe.txt")).read().splitlines()
+    assert len(got) == len(want) > 3000
+    bad = [(g, w) for g, w in zip(got, want) if g != w]
+    assert not bad, bad[:5]
+
+
+def test_every_preset_and_operator_of_the_kept_api_compiles(tmp_path):
+    """A caller's translation unit that names all 19 preset BSDFs of scene/bsdf.cuh:358-388 and the Vector3f operators a
+    scene description reaches (missing #1)."""
+    src = tmp_path / "caller.cpp"
+    src.write_text('''#include "raytracer_amd/pathtracer.hpp"
+BSDF *all_presets[] = {&mirror_bsdf, &refract_bsdf, &glass_bsdf, &aluminum_bsdf, &brass_bsdf, &copper_bsdf, &gold_bsdf, &iron_bsdf,
+                       &lead_bsdf, &mercury_bsdf, &platinum_bsdf, &silver_bsdf, &titanium_bsdf, &blue_metal_bsdf, &black_bsdf,
+                       &white_bsdf, &red_bsdf, &green_bsdf, &blue_bsdf};
+int main() {
+  Vector3f a(1, 2, 3), b(.5f);
+  a /= 2; a *= 3; a -= b; a += b;
+  Vector3f c = 2.f * a + a * 2.f - a / 3.f + 1.f / a;
+  float d = a.dot(b) + a.norm2() + c.illum() + c[0] + c.r;
+  Vector2f p(1, 2); Matrix3f M; Vector3f e = M.T() * c;
+  std::vector<Primitive *> prims;
+  for (BSDF *m: all_presets) prims.push_back(new Primitive(PrimitiveFactory::createSphere(e, d, m)));
+  static_assert(sizeof(Vector3f) == 12 && sizeof(Vector2f) == 8 && sizeof(Matrix3f) == 36, "layouts of the reference (SURVEY 8)");
+  return gold_bsdf.rec.type == BSDF::MICROFACET && gold_bsdf.rec.p[0] == 0.05f && (a == a) ? 0 : 1;
+}
+''')
+    r = _gxx(["-fsyntax-only", str(src)])
+    assert r.returncode == 0, r.stderr[-2000:]
