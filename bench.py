@@ -93,9 +93,10 @@ def launch_ranks(n, script, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
-    for ln in proc.stdout:
-        sys.stdout.write(ln)
-        sys.stdout.flush()
+    for ln in proc.stdout:                                  # rank 0's JSON line to stdout, anything else a rank printed (gloo's
+        dst = sys.stdout if ln.startswith("{") else sys.stderr      # connection notices) to stderr: stdout stays ONE JSON line
+        dst.write(ln)
+        dst.flush()
     return proc.wait()
 
 

@@ -24,7 +24,7 @@ def _film_check(s, g, key, travs=(0, 1), fabs_key="_rgb_fabs", **opt):
         same = (img == want).mean()
         assert same >= 0.999, f"{key}, traversal {trav}: only {same:.5f} of the film bytes equal the reference's"
         fd = film_delta(f"configs/{key}{fabs_key} traversal {trav}", img, want)
-        assert fd["by_more"] <= 3e-4 * fd["bytes"], fd       # beyond one tonemap level: paths that changed (test_gpu_parity.FILM_BY_MORE)
+        assert fd["by_more"] <= 1e-4 * fd["bytes"], fd       # beyond one tonemap level: paths that changed (test_gpu_parity.FILM_BY_MORE)
         assert abs(img.mean() - want.mean()) < 0.05
         assert s.last["traversal_used"] == trav
 

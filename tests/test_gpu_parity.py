@@ -199,7 +199,8 @@ def test_trace_edge_cases(mirt, oracle):
     s.close()
 
 
-FILM_BY_MORE = 3e-4          # share of film bytes allowed to differ by more than one level (measured: profiles/r3_film_delta.txt)
+FILM_BY_MORE = 1e-4          # share of film bytes allowed to differ by more than one level (measured on all 16 reference films,
+                             # both traversals: 0 differing bytes at all, profiles/r3_film_delta.txt)
 
 
 @pytest.mark.parametrize("key", list(SCENES))
