@@ -99,9 +99,9 @@ __device__ __forceinline__ void slot_to_pixel(const RenderArgs &a, uint32_t slot
 }
 
 // ============================================================================================ k_init
-__global__ void k_init(RenderArgs a) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= a.n_slots) return;
+// A slot's state before its first sample: the reference's seed procedure (renderer.cuh:50-51) for its pixel, sample index 1,
+// no ray; slots that cover no pixel (ragged tiles) are finished from the start.
+__device__ __forceinline__ uint4 initial_state(const RenderArgs &a, uint32_t s) {
   uint32_t px, py;
   bool valid;
   slot_to_pixel(a, s, px, py, valid);
@@ -115,6 +115,14 @@ __global__ void k_init(RenderArgs a) {
     for (int k = 0; k < 10; k++) rng_next(r);                        // renderer.cuh:51
     st.x = r.state;
   }
+  return st;
+}
+
+// (mirt_primary_hits only: a frame's first k_logic initialises its slots itself, RenderArgs::first)
+__global__ void k_init(RenderArgs a) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.n_slots) return;
+  const uint4 st = initial_state(a, s);
   a.st[s] = st;
   a.mask[s] = make_float4(1, 1, 1, 0);
   a.total[s] = make_float4(0, 0, 0, 0);
@@ -194,7 +202,7 @@ __device__ __forceinline__ const RenderArgs &late_args(const RenderArgs &entry) 
 }
 
 template<bool MF>
-__device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t s, const uint4 st, Emit &em) {
+__device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t s, const uint4 st, Emit &em, const bool first = false) {
   const uint32_t flags0 = st.z & 0xFF;
   uint32_t n_shadow = (st.z >> 8) & 0xFFFF;
   const bool has_ray = (flags0 & F_HAS_RAY) != 0;
@@ -202,7 +210,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t 
   // ---- 0. every load this slot can need, issued in dependency order before anything waits on one of them
   float4 h = make_float4(0, 0, 0, u2f(0xFFFFFFFFu));
   if (has_ray) h = a0.hit[s];
-  const float4 tot4 = a0.total[s];
+  const float4 tot4 = first ? make_float4(0, 0, 0, 0) : a0.total[s];     // (a frame's first iteration: nothing to read yet)
   float4 acc4 = make_float4(0, 0, 0, 0);              // loaded when a sample is finished (once in a few iterations)
   float4 m4 = make_float4(0, 0, 0, 0), ro = m4, rd = m4, dm = m4, sc0 = m4, sc1 = m4;
   uint32_t occ0 = 1, occ1 = 1;
@@ -449,7 +457,9 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t 
 #else
 #define MIRT_LOGIC_ATTR
 #endif
-template<bool MF>
+// FIRST: the frame's first launch (RenderArgs::first), which also initialises the slots.  An instantiation of its own: the
+// initialisation costs k_logic 8 VGPRs and with them a resident wave per SIMD, which only one launch per frame should pay.
+template<bool MF, bool FIRST = false>
 __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
   __shared__ uint32_t wave_cnt[4][5];
   __shared__ uint32_t block_base[5], block_tot[5];
@@ -466,8 +476,20 @@ __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
     em.ext = 0; em.nsh = 0; em.cull = 0;
     if (i < n) {
       s = MF ? a.mf_queue[i] : (listed ? a.live_in[i] : i);
-      const uint4 st = a.st[s];
-      if (MF || !(st.z & F_DONE)) logic_slot<MF>(a, s, st, em);
+      if (!MF && FIRST) {
+        // the frame's first iteration doubles as its initialisation (no k_init launch, no state to read): every slot starts
+        // its first sample; the running sums start at zero
+        const uint4 st = initial_state(a, s);
+        if (st.z & F_DONE) {
+          a.st[s] = st;
+        } else {
+          a.accum[s] = make_float4(0, 0, 0, 0);
+          logic_slot<MF>(a, s, st, em, true);
+        }
+      } else {
+        const uint4 st = a.st[s];
+        if (MF || !(st.z & F_DONE)) logic_slot<MF>(a, s, st, em);
+      }
     }
     // (a slot that is not finished has just emitted something; one handed to the MICROFACET kernel is listed by that one)
     const uint64_t m0 = __ballot(em.ext == 1), m1 = __ballot(em.ext == 2), m2 = __ballot(em.nsh != 0),
@@ -1566,7 +1588,8 @@ hipError_t launch_init(const RenderArgs &a, hipStream_t st) {
 }
 hipError_t launch_logic(const RenderArgs &a, bool deferred_microfacet, hipStream_t st) {
   if (!deferred_microfacet) {
-    k_logic<false><<<(a.n_slots + 255) / 256, 256, 0, st>>>(a);
+    if (a.first) k_logic<false, true><<<(a.n_slots + 255) / 256, 256, 0, st>>>(a);
+    else k_logic<false><<<(a.n_slots + 255) / 256, 256, 0, st>>>(a);
   } else {
     const uint32_t blocks = (a.n_slots + 255) / 256;
     k_logic<true><<<blocks < 2048 ? blocks : 2048, 256, 0, st>>>(a);

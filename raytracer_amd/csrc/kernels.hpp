@@ -60,6 +60,7 @@ struct RenderArgs {
   // Housekeeping folded into k_logic so that an iteration costs no extra dispatches (host loop):
   uint32_t *clear_next;                   // k_logic<false>: workgroup 0 zeroes the control block of the NEXT iteration (three
   uint32_t clear_words;                   //   blocks rotate, so that block is idle now), clear_words words of it
+  uint32_t first;                         // k_logic<false>: the frame's first iteration - slots are initialised in place of k_init
 };
 
 struct TraceArgs {

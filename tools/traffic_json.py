@@ -7,7 +7,7 @@ import json
 import sys
 
 NAMES = {"mirt::k_trace_fast<false, false, false>": "k_trace_fast<closest>", "mirt::k_trace_fast<true, false, false>": "k_trace_fast<any>",
-         "mirt::k_logic<false>": "k_logic"}
+         "mirt::k_logic<false, false>": "k_logic"}
 rows = {}
 with open(sys.argv[1], newline="") as fh:
     for r in csv.DictReader(fh):
