@@ -306,6 +306,19 @@ int mirt_group_render(mirt_group *g, const mirt_camera *camera, const mirt_param
       if (mb->stats.iterations > stats->iterations) stats->iterations = mb->stats.iterations;
       if (mb->stats.render_ms > stats->render_ms) stats->render_ms = mb->stats.render_ms;
       if (mb->stats.total_ms > stats->total_ms) stats->total_ms = mb->stats.total_ms;
+      // work counters add up over the members, per-kernel times are the slowest member's
+      stats->logic_live_slots += mb->stats.logic_live_slots;
+      stats->logic_scanned_slots += mb->stats.logic_scanned_slots;
+      stats->closest_node_visits += mb->stats.closest_node_visits;
+      stats->closest_tri_tests += mb->stats.closest_tri_tests;
+      stats->shadow_node_visits += mb->stats.shadow_node_visits;
+      stats->shadow_tri_tests += mb->stats.shadow_tri_tests;
+      stats->closest_launches += mb->stats.closest_launches;
+      stats->shadow_launches += mb->stats.shadow_launches;
+      stats->logic_launches += mb->stats.logic_launches;
+      if (mb->stats.trace_closest_ms > stats->trace_closest_ms) stats->trace_closest_ms = mb->stats.trace_closest_ms;
+      if (mb->stats.trace_shadow_ms > stats->trace_shadow_ms) stats->trace_shadow_ms = mb->stats.trace_shadow_ms;
+      if (mb->stats.logic_ms > stats->logic_ms) stats->logic_ms = mb->stats.logic_ms;
     }
     stats->tonemap_table_exact = g->members[0]->stats.tonemap_table_exact;
     stats->traversal_used = g->members[0]->stats.traversal_used;
