@@ -1322,10 +1322,12 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
       const uint32_t nzw[2] = {ngz ? Q2.z : Q1.x, ngz ? Q2.w : Q1.y}, fzw[2] = {ngz ? Q1.x : Q2.z, ngz ? Q1.y : Q2.w};
       const uint32_t ch[8] = {C0.x, C0.y, C0.z, C0.w, C1.x, C1.y, C1.z, C1.w};
       const float far_limit = r.best_t;
-      // All eight slab tests first (straight-line VALU), then the choice of the child to enter, then the pushes.  The kernel
-      // is bound by VALU issue (~3900 wave instructions per ray before this form, most of them exec-mask bookkeeping around
-      // eight conditional pushes with their LDS / overflow split): the common case - the lane's pushes all fit its LDS
-      // part of the stack - is one compare, one masked ds_write and one add per child.
+      // All eight slab tests first (straight-line VALU), then the choice of the child to enter, then the pushes: the common
+      // case - the lane's pushes all fit its LDS part of the stack - is one compare, one masked ds_write and one add per
+      // child (the first form spent most of its instructions on exec-mask bookkeeping around eight conditional pushes with
+      // their LDS / overflow split).  Where the kernel stands now (profiles/r3_pmc_sq.json): 58 wave
+      // instructions per ray at 42 % of the lanes active; running alone its SIMDs are VALU-busy 68 % of the time and its
+      // waves parked on s_waitcnt 47 % of theirs; inside the overlapped frame resident waves are what it competes for.
       float key[8];
       uint32_t hits = 0;
 #pragma unroll
