@@ -60,8 +60,15 @@ def parse(argv=None):
                          "GPU, but every iteration shrinks to 1/N of the rays: 0.23 at N = 8)")
     ap.add_argument("--streams", type=int, default=0,
                     help="sample streams per pixel in flight (mirt_options.streams): same samples, fewer and larger wavefront "
-                         "iterations; 1 = one path per pixel at a time, the reference's order of summation; 0 (default) = 8 when "
-                         "a rank renders at least 16 samples per pixel, else 4 (measured: tools/streams64.sh, tools/share_sweep.sh)")
+                         "iterations; 1 = one path per pixel at a time, the reference's order of summation; 0 (default) = with "
+                         "the share pool 8 when a rank renders more than 32 samples per pixel, else 4 (tools/pool_streams.sh); "
+                         "without it 8 from 16 samples per pixel on (tools/streams64.sh, tools/share_sweep.sh)")
+    ap.add_argument("--shares", type=int, default=0,
+                    help="share pool (mirt_options.shares): the rank's samples of a pixel are cut into this many shares (planes), "
+                         "and the --streams path slots per pixel take (share, pixel) items of their 8x8 tile dynamically, so a "
+                         "tile's slots stay busy until the tile runs out of work; the image is exactly that of --streams W.  "
+                         "0 (default) = one share per sample, at most 64 (the largest divisor of the rank's sample count that is "
+                         "<= 64); 1 = off (tools/pool_ab.sh: 122.9 -> 119.6 ms at 64 spp, 19.6 -> 18.6 ms for the 8-spp share)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (what the driver runs); gloo = rehearsal of the N > 1 path on a box "
                          "with fewer GPUs than ranks: ranks share the GPUs and the buffers are summed through host memory")
@@ -171,7 +178,8 @@ def traffic_table(args, world):
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             d = json.load(fh)
         mine = {"workload": args.workload, "width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth,
-                "streams": args.streams, "traversal": args.traversal, "n_gpus": world}
+                "streams": args.streams, "shares": pick_shares(args.spp, args.shares, args.streams) if args.rng == 1 else 0,
+                "traversal": args.traversal, "n_gpus": world}
         if d.get("configuration") != mine:
             return {}, None
         return {k: v["hbm_bytes_per_launch"] for k, v in d["kernels"].items()}, d.get("source")
@@ -245,6 +253,16 @@ def logic_bytes(st, K):
             + sh * (48 + 4 + 20) + paths * 32)
 
 
+def pick_shares(spp, want, streams):
+    """mirt_options.shares for a rank that renders `spp` samples per pixel: `want` (0: as many as samples, at most 64) rounded
+    down to a divisor of spp; 0 (pool off) when that is not more than the sample streams."""
+    if want == 1 or spp < 2:
+        return 0
+    cap = min(spp, want if want > 0 else 64)
+    w = max(d for d in range(1, cap + 1) if spp % d == 0)
+    return w if w > max(1, streams) else 0
+
+
 def main(argv=None, backend_cls=GpuBackend, script=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
@@ -274,15 +292,23 @@ def main(argv=None, backend_cls=GpuBackend, script=None):
 
     if args.streams == 0:
         spp_rank = args.spp // world if (world > 1 and args.partition == "spp") else args.spp
-        args.streams = 8 if spp_rank >= 16 else 4
+        if args.shares != 1 and args.rng == 1:
+            args.streams = 8 if spp_rank > 32 else 4
+        else:
+            args.streams = 8 if spp_rank >= 16 else 4
+
+    # share pool: shares must divide the samples THIS rank renders (the last rank of an spp partition takes the remainder)
+    from raytracer_amd import dist as rdist
+
+    spp_mine = rdist.spp_slices(args.spp, world)[rank][1] if (world > 1 and args.partition == "spp" and args.spp >= world) else args.spp
+    shares = pick_shares(spp_mine, args.shares, args.streams) if args.rng == 1 else 0
 
     accum = be.setup()
     w, h = args.width, args.height
 
     # the timed steps carry HIP events around the dominant kernel's launches only (every event pair costs a little)
     opt = dict(rng_mode=args.rng, traversal=args.traversal, profile_closest=True, streams=args.streams if args.rng == 1 else 0,
-               cull_zero=args.cull_zero)
-    from raytracer_amd import dist as rdist
+               cull_zero=args.cull_zero, shares=shares)
 
     if world > 1 and args.partition == "spp" and args.spp < world:
         raise SystemExit("spp partition needs at least one sample per rank: use --partition tile")
@@ -359,7 +385,7 @@ def report(be, args, opt, stats, rays, ms_per_step, world, accum):
     w, h = args.width, args.height
     # traversal work per ray (counting build of the same kernels, one untimed reduced-spp frame)
     cnt = be.render_accum(accum, **{**opt, "spp": min(4, args.spp), "batch": args.spp + 1, "count": True, "sample_count": 0,
-                                    "sample_begin": 0})
+                                    "sample_begin": 0, "shares": 0})
     # one more untimed frame with events around EVERY launch: the per-kernel lines of the roofline (the timed steps carry
     # events around the closest-hit launches only)
     split = be.render_accum(accum, **{**opt, "profile": True, "profile_closest": False, "sample_count": 0, "sample_begin": 0})
@@ -410,7 +436,8 @@ def report(be, args, opt, stats, rays, ms_per_step, world, accum):
                 else "synthetic (procedural stand-in scene: the reference's .obj meshes are absent)",
         "config": {"workload": f"{args.workload} {sd.n} tris, {w}x{h}, {args.spp} spp, depth {args.depth}, "
                                f"{len(sd.lights)} light{'s' if len(sd.lights) != 1 else ''}, rng {'counter' if opt['rng_mode'] else 'xorshift'}, "
-                               f"traversal {args.traversal}, {opt['streams']} sample streams",
+                               f"traversal {args.traversal}, {opt['streams']} sample streams"
+                               + (f", pool of {opt['shares']} shares" if opt.get("shares") else ""),
                    "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
                    "reference_walk_rays_per_frame": sum(s["exact_fallback_rays"] for s in stats) / max(1, args.steps),
                    "scene_build_s": be.build_s, "builder": args.builder or "host", "build_ms": be.build_ms},

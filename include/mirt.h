@@ -103,7 +103,19 @@ typedef struct mirt_options {
                                the k-th contiguous share of the pixel's samples into its own partial sum; the partial sums are
                                added in stream order at the end).  Same samples, S times fewer and S times larger wavefront
                                iterations; like an spp slice it switches the adaptive stop off.  At most 16. */
-  uint32_t reserved[6];
+  uint32_t shares;          /* rng_mode 1 only, 0 = off: the share pool.  A pixel's samples are cut into W = shares contiguous shares,
+                               each summed in sample order into a partial sum of its own, the partial sums added in share
+                               order - exactly the image of streams = W - but only `streams` paths per pixel are in flight:
+                               a path slot that has finished a share takes the next unrendered (share, pixel) of the frame,
+                               so every slot stays busy until the frame runs out of work instead of idling while the
+                               pixels with long paths finish (no reference counterpart).  Needs
+                               shares > streams (else it is ignored), shares <= samples and samples % shares == 0; memory:
+                               one float4 plane of the image per share. */
+  uint32_t pool_group;      /* share pool: a slot takes its next (share, pixel) from the pool of its home group, the
+                               pool_group neighbouring pixel slots (whole 8x8 tiles: a multiple of 64) around its own pixel,
+                               so that it keeps rendering its neighbourhood; 0 = the library's default (64, MIRT_POOL_GROUP).
+                               Any value gives the same image; it trades balance (large) against locality (small). */
+  uint32_t reserved[4];
 } mirt_options;
 
 typedef struct mirt_stats {

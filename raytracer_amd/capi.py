@@ -49,7 +49,7 @@ class Options(C.Structure):
     _fields_ = [("rng_mode", C.c_uint32), ("seed", C.c_uint32), ("traversal", C.c_uint32), ("tile_rank", C.c_uint32),
                 ("tile_world", C.c_uint32), ("sample_begin", C.c_uint32), ("sample_count", C.c_uint32),
                 ("glass_int_abs", C.c_uint32), ("flags", C.c_uint32), ("streams", C.c_uint32),
-                ("reserved", C.c_uint32 * 6)]
+                ("shares", C.c_uint32), ("pool_group", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class BuildOptions(C.Structure):
@@ -241,7 +241,7 @@ class Scene:
     @staticmethod
     def options(rng_mode=0, seed=0, traversal=0, tile_rank=0, tile_world=1, sample_begin=0, sample_count=0,
                 glass_int_abs=0, profile=False, count=False, streams=0, accumulate=False, profile_closest=False,
-                cull_zero=False):
+                cull_zero=False, shares=0, pool_group=0):
         o = Options()
         o.rng_mode, o.seed, o.traversal = rng_mode, seed, traversal
         o.tile_rank, o.tile_world = tile_rank, tile_world
@@ -249,6 +249,8 @@ class Scene:
         o.flags = (1 if profile else 0) | (2 if count else 0) | (4 if accumulate else 0) | (8 if profile_closest else 0) | \
             (16 if cull_zero else 0)
         o.streams = streams
+        o.shares = shares
+        o.pool_group = pool_group
         return o
 
     def render(self, w, h, spp=4, spl=1, batch=64, tol=0.05, depth=4, leaf=4, **opt):

@@ -79,6 +79,7 @@ struct Global {
   hipEvent_t pipe_ev[MAX_PIPES] = {};
   int pipes = 2;                        // MIRT_PIPES: independent wavefront loops per frame (1 ... 4; needs as many sample streams)
   bool one_pipe = false;
+  uint32_t pool_group = 64;             // MIRT_POOL_GROUP: pixel slots per home group of the share pool (a multiple of 64)
   uint32_t live_16th = 4;               // MIRT_LIVE_16TH: k_logic walks the live-slot list once it is below this share of the slots
   bool blocks_forced = false;           // MIRT_BLOCKS_PER_CU given
   float table[256];
@@ -126,6 +127,7 @@ enum {
 };
 constexpr int CTRL_BLOCKS = 3;                           // per pipe: iteration i uses block i % 3 and clears block (i + 1) % 3
 constexpr size_t TAIL_BYTES = (size_t) CTRL_BLOCKS * MAX_PIPES * CTRL_WORDS * 4 + MAX_PIPES * 16 * 8;   // Global::h_tail
+constexpr size_t RAY_STATS_BYTES = (size_t) MAX_PIPES * 16 * 8;
 constexpr int HSLOT = 8;                                 // words per host ring slot: 5 queue counters, 2 spare, stamp
 
 // ---- mirt_trace_static: everything its kernels need beyond the caller's inputs and outputs lives in ONE file-scope device
@@ -252,6 +254,10 @@ int mirt_init(int device) {
   if (const char *s = getenv("MIRT_LIVE_16TH")) {
     int v = atoi(s);
     if (v >= 0 && v <= 16) G.live_16th = (uint32_t) v;
+  }
+  if (const char *s = getenv("MIRT_POOL_GROUP")) {
+    int v = atoi(s);
+    if (v >= 64 && (v % 64) == 0) G.pool_group = (uint32_t) v;
   }
   if (const char *s = getenv("MIRT_STATIC_16TH")) {
     int v = atoi(s);
@@ -674,7 +680,7 @@ int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
   HIPCHK(s->live[0].ensure(n * 4));
   HIPCHK(s->live[1].ensure(n * 4));
   HIPCHK(s->ctrl.ensure(CTRL_BLOCKS * MAX_PIPES * CTRL_WORDS * 4));    // per pipe three blocks in rotation
-  HIPCHK(s->ray_stats.ensure(MAX_PIPES * 16 * 8));
+  HIPCHK(s->ray_stats.ensure(RAY_STATS_BYTES + 256 + 4 * ((size_t) n_slots / 64 + 1)));   // + the share pool's counters (at most one per tile)
   return MIRT_OK;
 }
 
@@ -788,33 +794,48 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   if (o.traversal == 0 && !s->fast_ok) o.traversal = 1;
   if (o.tile_world > 1 && o.tile_rank >= o.tile_world) return fail(MIRT_E_ARG, "tile_rank >= tile_world");
   uint32_t streams = o.streams > 1 ? o.streams : 1;
-  const bool sliced = o.sample_count != 0 || o.sample_begin != 0 || streams > 1 || (o.flags & 4u);
+  const bool sliced = o.sample_count != 0 || o.sample_begin != 0 || streams > 1 || o.shares > 1 || (o.flags & 4u);
   if (sliced && o.rng_mode != 1)
     return fail(MIRT_E_ARG, "spp slices and sample streams need rng_mode 1 (the xorshift stream is sequential per pixel)");
   if (streams > 16) return fail(MIRT_E_ARG, "at most 16 sample streams");
-  {
-    const uint32_t spp_here = o.sample_count ? o.sample_count : prm->samples_per_pixel;
-    if (streams > spp_here) streams = spp_here ? spp_here : 1;
+  const uint32_t spp_here = o.sample_count ? o.sample_count : prm->samples_per_pixel;
+  if (streams > spp_here) streams = spp_here ? spp_here : 1;
+  // Share pool: W = o.shares planes per pixel, `streams` slots per pixel slot that take (share, pixel) items dynamically.
+  // W <= streams is plain sample streams.  Equal shares only: the kernel prices every item at spp / W samples.
+  uint32_t shares = streams;
+  if (o.shares > streams) {
+    if (o.rng_mode != 1) return fail(MIRT_E_ARG, "the share pool needs rng_mode 1 (the xorshift stream is sequential per pixel)");
+    if (o.shares > spp_here) return fail(MIRT_E_ARG, "more shares than samples per pixel");
+    if (spp_here % o.shares != 0) return fail(MIRT_E_ARG, "shares must divide the number of samples per pixel");
+    if (o.shares > 4096) return fail(MIRT_E_ARG, "at most 4096 shares");
+    shares = o.shares;
   }
+  const bool pool = shares > streams;
   const uint64_t K64 = (uint64_t) s->n_lights * prm->samples_per_light;
   if (K64 > 0xFFFF) return fail(MIRT_E_LIMIT, "more than 65535 shadow rays per hit");
   const uint32_t K = (uint32_t) K64;
   const Partition part = make_partition(w, h, o);
   const uint64_t total_slots = (uint64_t) part.n_slots * streams;
   if (total_slots * (K ? K : 1) >= (1ull << 32)) return fail(MIRT_E_LIMIT, "shadow queue beyond 2^32 entries");
+  if ((uint64_t) part.n_slots * shares >= (1ull << 32) - 1) return fail(MIRT_E_LIMIT, "more than 2^32 share items");
   auto wall0 = std::chrono::steady_clock::now();
 
   int rc = ensure_work(s, (uint32_t) total_slots, K);
   if (rc) return rc;
   // progressive pass (flags bit 2): the samples are added to what accum_dev already holds, through the plane buffer
   const bool accumulate = (o.flags & 4u) != 0;
-  const bool via_planes = streams > 1 || accumulate;
+  const bool via_planes = shares > 1 || accumulate;
   if (accumulate && o.rng_mode != 1) return fail(MIRT_E_ARG, "progressive passes need rng_mode 1");
-  if (via_planes) HIPCHK(s->planes.ensure((size_t) streams * w * h * 16));
+  if (via_planes) HIPCHK(s->planes.ensure((size_t) shares * w * h * 16));
 
   RenderArgs a;
   memset(&a, 0, sizeof a);
   a.n_slots = (uint32_t) total_slots; a.n_pixel_slots = part.n_slots; a.streams = streams;
+  a.shares = shares; a.pool = pool ? 1u : 0u;
+  if (o.pool_group % 64u) return fail(MIRT_E_ARG, "pool_group must be a multiple of 64 (whole 8x8 tiles)");
+  a.pool_group = o.pool_group ? o.pool_group : G.pool_group;
+  a.pool_next = (uint32_t *) ((char *) s->ray_stats.p + RAY_STATS_BYTES + 256);
+  const size_t pool_groups = pool ? ((size_t) part.n_slots + a.pool_group - 1) / a.pool_group : 0;
   a.width = w; a.height = h;
   a.tiles_x = part.tiles_x; a.tiles_y = part.tiles_y; a.tile_rank = part.rank; a.tile_world = part.world;
   a.rng_mode = o.rng_mode; a.seed = o.seed; a.sample_begin = o.sample_begin;
@@ -862,8 +883,8 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   const bool foreign_pixels = part.world > 1 || part.n_slots == 0;
   if (!accumulate && foreign_pixels)
     HIPCHK(hipMemsetAsync(accum_dev, 0, (size_t) w * h * 16, G.stream));
-  if (via_planes && foreign_pixels) HIPCHK(hipMemsetAsync(s->planes.p, 0, (size_t) streams * w * h * 16, G.stream));
-  HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, MAX_PIPES * 128, G.stream));
+  if (via_planes && foreign_pixels) HIPCHK(hipMemsetAsync(s->planes.p, 0, (size_t) shares * w * h * 16, G.stream));
+  HIPCHK(hipMemsetAsync(s->ray_stats.p, 0, RAY_STATS_BYTES + 256 + 4 * pool_groups, G.stream));
   HIPCHK(hipMemsetAsync(s->ctrl.p, 0, CTRL_BLOCKS * MAX_PIPES * CTRL_WORDS * 4, G.stream));
   HIPCHK(hipEventRecord(evA, G.stream));
 
@@ -919,7 +940,8 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
       HIPCHK(hipEventRecord(G.pipe_ev[0], G.stream));
       for (int p = 1; p < n_pipes; p++) HIPCHK(hipStreamWaitEvent(G.pstream[p], G.pipe_ev[0], 0));
     }
-    const uint64_t max_iters = (uint64_t) a.spp * ((uint64_t) a.max_depth + 3) + 8;
+    // (share pool: a slot renders items until the frame runs out of them - at most (1/streams + 1/shares) of a pixel's samples)
+    const uint64_t max_iters = (uint64_t) a.spp * ((uint64_t) a.max_depth + 3) * (pool ? 2u : 1u) + 8;
     bool all_done = false;
     while (!all_done) {
       all_done = true;
@@ -1030,7 +1052,7 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     }
   }
   if (via_planes && part.n_slots)
-    HIPCHK(launch_sum_planes(s->planes.as<float4>(), streams, w * h, (float4 *) accum_dev, accumulate ? 1 : 0, G.stream));
+    HIPCHK(launch_sum_planes(s->planes.as<float4>(), shares, w * h, (float4 *) accum_dev, accumulate ? 1 : 0, G.stream));
   // error flags and ray statistics ride home behind the frame's last kernel, into pinned memory: no blocking copies after it
   constexpr size_t CTRL_ALL = (size_t) CTRL_BLOCKS * MAX_PIPES * CTRL_WORDS * 4;
   HIPCHK(hipEventRecord(evB, G.stream));

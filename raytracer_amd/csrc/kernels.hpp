@@ -16,7 +16,7 @@ constexpr int LDS_STACK = MIRT_LDS_STACK;        // traversal-stack entries per 
 constexpr int BVH2_STACK = 64;       // k_trace2 (the reference uses 32 unchecked, util/misc.cuh:19)
 
 // per-slot flag bits (RenderArgs::st[].z low byte)
-enum : uint32_t { F_DONE = 1, F_HAS_RAY = 2, F_PENDING = 4, F_AHEAD = 8 };
+enum : uint32_t { F_DONE = 1, F_HAS_RAY = 2, F_PENDING = 4, F_AHEAD = 8, F_NEWITEM = 16 };
 // Queue counters (word offsets into RenderArgs::qcount).  Every counter that kernels update with atomics lives on a
 // 128-byte line of its own: same-address atomics retire at ~11 ns each on MI355X (tools/micro/atomic_rate.hip) and
 // counters sharing a line queue up behind each other.
@@ -61,6 +61,19 @@ struct RenderArgs {
   uint32_t *clear_next;                   // k_logic<false>: workgroup 0 zeroes the control block of the NEXT iteration (three
   uint32_t clear_words;                   //   blocks rotate, so that block is idle now), clear_words words of it
   uint32_t first;                         // k_logic<false>: the frame's first iteration - slots are initialised in place of k_init
+  // Share pool (mirt_options.shares = W > streams, counter RNG): a pixel's samples are cut into W contiguous shares, each summed
+  // in sample order into a plane of its own (out_accum holds W planes, added in share order at the end), but only `streams`
+  // slots per pixel slot exist.  A work item is (share, pixel slot) = share * n_pixel_slots + pixel slot; slot s starts with
+  // item stream_first * n_pixel_slots + s - the static assignment - and a slot that has finished its item takes the next one
+  // from the pool of its home group (kernels.hip, pool_item): the slots of a neighbourhood stay busy until the neighbourhood
+  // runs out of items, instead of the slots with short paths idling while the ones with long paths finish their fixed share
+  // (DESIGN.md 5, round 3).
+  // total[].w (s1, only read by the adaptive stop, which is off here) carries the item of the path in flight, accum[].w the
+  // item the accumulator belongs to - they differ while a finished share waits for its last shadow rays (F_NEWITEM).
+  uint32_t shares;                        // planes per pixel: W, or `streams` when the pool is off (1: a single accumulator)
+  uint32_t pool;                          // 1: items beyond the static ones come from pool_next
+  uint32_t pool_group;                    // pixel slots per home group (a multiple of 64): a slot takes items of its own group only
+  uint32_t *pool_next;                    // one counter per group, shared by the pipes: items (streams + j / size, j % size) handed out
 };
 
 struct TraceArgs {

@@ -16,7 +16,7 @@ with open(sys.argv[1], newline="") as fh:
 out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (one pass each) -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0",
        "correction": "MI355X_MICROARCH.md, HBM: FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> doubled; WRITE_SIZE exact; unit KiB",
        "source": sys.argv[2],
-       "configuration": {"workload": "conference*", "width": 1920, "height": 1080, "spp": 64, "depth": 8, "streams": 8,
+       "configuration": {"workload": "conference*", "width": 1920, "height": 1080, "spp": 64, "depth": 8, "streams": 8, "shares": 64,
                          "traversal": 0, "n_gpus": 1},
        "kernels": {}}
 for name, c in rows.items():
