@@ -894,8 +894,10 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   while (n_pipes > 1 && (uint32_t) n_pipes > streams) n_pipes /= 2;
   // with two pipes four persistent launches share the GPU: 4 workgroups per CU each measured best (tools/sweep_env.sh)
   const uint32_t pipe_blocks = (n_pipes >= 2 && !G.blocks_forced) ? (n_pipes == 2 ? 4u : 3u) : 0u;
-  // (the closest-hit launches are what the frame waits for: the shadow launches get by with one workgroup per CU less)
-  uint32_t shadow_blocks = pipe_blocks ? pipe_blocks - 1 : 0u;
+  // (the closest-hit launches are what the frame waits for: the shadow launches get by with one workgroup per CU less -
+  // except under the share pool, whose launches stay full until the frame's end: tools/shadow_blocks.sh, conference* 64 spp
+  // 118.8 -> 116.0 ms with 4, the other workloads and the smaller shares unchanged)
+  uint32_t shadow_blocks = pipe_blocks ? (pool ? pipe_blocks : pipe_blocks - 1) : 0u;
   if (const char *e = getenv("MIRT_SHADOW_BLOCKS")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 16) shadow_blocks = (uint32_t) v;

@@ -25,6 +25,9 @@
 #ifndef MIRT_LOGIC_WAVES
 #define MIRT_LOGIC_WAVES 0   // k_logic: amdgpu_waves_per_eu(min); 0 = the compiler's choice.  4..6 measured: nothing / slower (spills)
 #endif
+#ifndef MIRT_LOGIC_EAGER
+#define MIRT_LOGIC_EAGER 1   // k_logic: 1 = a slot's hit and running total are requested together with its state record (one dependent
+#endif                       // memory round trip less, 32 B wasted per finished slot a launch looks at); 2 = its shadow results too
 #ifndef MIRT_ADMIT_K
 #define MIRT_ADMIT_K 1.0e-5f   // own-box admission pre-test: barycentric margin factor
 #endif
@@ -239,26 +242,38 @@ struct SlotTail {
 };
 constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
 
+// What k_logic requests together with a slot's state record, before it knows what the slot needs (MIRT_LOGIC_EAGER).
+struct SlotEager {
+  float4 h, tot4, dm, sc0, sc1;
+  uint32_t occ0, occ1;
+};
 template<bool MF>
-__device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t s, const uint4 st, Emit &em, SlotTail &T, const bool first = false) {
+__device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t s, const uint4 st, Emit &em, SlotTail &T, const bool first = false,
+                                           const SlotEager *eager = nullptr) {
   const uint32_t flags0 = st.z & 0xFF;
   uint32_t n_shadow = (st.z >> 8) & 0xFFFF;
   const bool has_ray = (flags0 & F_HAS_RAY) != 0;
 
   // ---- 0. every load this slot can need, issued in dependency order before anything waits on one of them
   float4 h = make_float4(0, 0, 0, u2f(0xFFFFFFFFu));
-  if (has_ray) h = a0.hit[s];
-  const float4 tot4 = first ? make_float4(0, 0, 0, 0) : a0.total[s];     // (a frame's first iteration: nothing to read yet)
+  if (has_ray) h = (MIRT_LOGIC_EAGER >= 1 && eager) ? eager->h : a0.hit[s];
+  const float4 tot4 = first ? make_float4(0, 0, 0, 0)                    // (a frame's first iteration: nothing to read yet)
+                            : ((MIRT_LOGIC_EAGER >= 1 && eager) ? eager->tot4 : a0.total[s]);
   float4 acc4 = make_float4(0, 0, 0, 0);              // loaded when a sample is finished (once in a few iterations)
   float4 m4 = make_float4(0, 0, 0, 0), ro = m4, rd = m4, dm = m4, sc0 = m4, sc1 = m4;
   uint32_t occ0 = 1, occ1 = 1;
   if (n_shadow) {
-    dm = a0.dmask[s];
-    occ0 = a0.sh_occ[s];
-    sc0 = a0.sh_c[s];
-    if (n_shadow > 1) {
-      occ1 = a0.sh_occ[(size_t) a0.n_slots + s];
-      sc1 = a0.sh_c[(size_t) a0.n_slots + s];
+    if (MIRT_LOGIC_EAGER >= 2 && eager) {
+      dm = eager->dm; occ0 = eager->occ0; sc0 = eager->sc0;
+      if (n_shadow > 1) { occ1 = eager->occ1; sc1 = eager->sc1; }
+    } else {
+      dm = a0.dmask[s];
+      occ0 = a0.sh_occ[s];
+      sc0 = a0.sh_c[s];
+      if (n_shadow > 1) {
+        occ1 = a0.sh_occ[(size_t) a0.n_slots + s];
+        sc1 = a0.sh_c[(size_t) a0.n_slots + s];
+      }
     }
   }
   const int32_t prim = (int32_t) f2u(h.w);
@@ -617,7 +632,25 @@ __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
         }
       } else {
         const uint4 st = a.st[s];
+#if MIRT_LOGIC_EAGER
+        SlotEager eg;
+        eg.h = a.hit[s];
+        eg.tot4 = a.total[s];
+        eg.dm = eg.sc0 = eg.sc1 = make_float4(0, 0, 0, 0);
+        eg.occ0 = eg.occ1 = 1;
+#if MIRT_LOGIC_EAGER >= 2
+        eg.dm = a.dmask[s];
+        eg.occ0 = a.sh_occ[s];
+        eg.sc0 = a.sh_c[s];
+        if (K >= 2) {
+          eg.occ1 = a.sh_occ[(size_t) a.n_slots + s];
+          eg.sc1 = a.sh_c[(size_t) a.n_slots + s];
+        }
+#endif
+        if (MF || !(st.z & F_DONE)) logic_slot<MF>(a, s, st, em, T, false, &eg);
+#else
         if (MF || !(st.z & F_DONE)) logic_slot<MF>(a, s, st, em, T);
+#endif
       }
     }
     // Share pool: the slots that have finished their item take the next ones of their home group, one atomic per wave and
