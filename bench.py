@@ -67,8 +67,8 @@ def parse(argv=None):
                     help="share pool (mirt_options.shares): the rank's samples of a pixel are cut into this many shares (planes), "
                          "and the --streams path slots per pixel take (share, pixel) items of their 8x8 tile dynamically, so a "
                          "tile's slots stay busy until the tile runs out of work; the image is exactly that of --streams W.  "
-                         "0 (default) = one share per sample, at most 64 (the largest divisor of the rank's sample count that is "
-                         "<= 64); 1 = off (tools/pool_ab.sh: 122.9 -> 119.6 ms at 64 spp, 19.6 -> 18.6 ms for the 8-spp share)")
+                         "0 (default) = one share per sample when the rank renders at most 64 samples per pixel, off above that; "
+                         "1 = off (tools/pool_ab.sh: 122.9 -> 119.6 ms at 64 spp, 19.6 -> 18.6 ms for the 8-spp share)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (what the driver runs); gloo = rehearsal of the N > 1 path on a box "
                          "with fewer GPUs than ranks: ranks share the GPUs and the buffers are summed through host memory")
@@ -254,9 +254,12 @@ def logic_bytes(st, K):
 
 
 def pick_shares(spp, want, streams):
-    """mirt_options.shares for a rank that renders `spp` samples per pixel: `want` (0: as many as samples, at most 64) rounded
-    down to a divisor of spp; 0 (pool off) when that is not more than the sample streams."""
-    if want == 1 or spp < 2:
+    """mirt_options.shares for a rank that renders `spp` samples per pixel: `want` rounded down to a divisor of spp; 0 (pool
+    off) when that is not more than the sample streams.  want = 0, the default: one share per sample up to 64 samples per
+    pixel, and no pool above that - a slot that renders 32 or more samples in sequence is balanced by their number, and the
+    pool's item fetches in k_logic only cost (buddha* 256 spp: 304 ms without, 312 ms with; sportsCar* 4K 1024 spp: 6.52 s /
+    6.63 s; conference* 64 spp: 118.8 / 116.0 ms; tools/pool_ab.sh, gpurun_out/buddha_pool_probe.txt)."""
+    if want == 1 or spp < 2 or (want == 0 and spp > 64):
         return 0
     cap = min(spp, want if want > 0 else 64)
     w = max(d for d in range(1, cap + 1) if spp % d == 0)
@@ -292,7 +295,7 @@ def main(argv=None, backend_cls=GpuBackend, script=None):
 
     if args.streams == 0:
         spp_rank = args.spp // world if (world > 1 and args.partition == "spp") else args.spp
-        if args.shares != 1 and args.rng == 1:
+        if args.shares != 1 and args.rng == 1 and (args.shares > 1 or spp_rank <= 64):
             args.streams = 8 if spp_rank > 32 else 4
         else:
             args.streams = 8 if spp_rank >= 16 else 4
