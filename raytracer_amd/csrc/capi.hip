@@ -89,6 +89,7 @@ struct Global {
   uint32_t *h_film = nullptr;            // pinned: the packed film on its way to the caller
   size_t h_film_words = 0;
   hipEvent_t film_ev[8] = {};
+  WorkerPool *film_pool = nullptr;       // host threads that widen the film as its pieces land (mirt_tonemap), kept across frames
   uint32_t *h_counts = nullptr;          // host-mapped, coherent: MAX_PIPES x RING slots of HSLOT words, written by k_logic
   uint32_t *d_counts = nullptr;          // the same memory as the device sees it
   uint32_t *h_tail = nullptr;            // pinned: a frame's control blocks (error flags) and ray statistics, copied before the frame's last event
@@ -293,6 +294,8 @@ void mirt_shutdown(void) {
   G.h_tail = nullptr;
   if (G.h_film) (void) hipHostFree(G.h_film);
   for (auto e: G.film_ev) if (e) (void) hipEventDestroy(e);
+  delete G.film_pool;
+  G.film_pool = nullptr;
   for (auto e: G.pool) (void) hipEventDestroy(e);
   G.d_table.release();
   G.d_rgb.release();
@@ -1150,15 +1153,17 @@ int mirt_tonemap(const void *accum_dev, uint32_t width, uint32_t height, int32_t
   const hipEvent_t *film_ev = G.film_ev;                                 // (the context is per thread: the workers get copies)
   const uint32_t *h_film = G.h_film;
   // (two workers per piece, each widening half of it: what is left after the last piece has landed is a sixteenth of the film)
-  parallel_for(2 * PIECES, [&](size_t j0, size_t j1) {
-    for (size_t j = j0; j < j1; j++) {
-      const size_t k = j / 2;
-      if (hipEventSynchronize(film_ev[k]) != hipSuccess) { bad.store(1); continue; }
-      const size_t mid = (cut[k] + (cut[k + 1] - cut[k]) / 2) & ~(size_t) 3;
-      const size_t lo = (j & 1) ? (mid > cut[k] ? mid : cut[k]) : cut[k], hi = (j & 1) ? cut[k + 1] : (mid > cut[k] ? mid : cut[k]);
-      if (hi > lo) widen_film(h_film + lo, hi - lo, rgb_out + 3 * lo);
-    }
-  }, 1);
+  if (!G.film_pool) {
+    const unsigned t = host_threads();
+    G.film_pool = new WorkerPool(t > 1 ? (t > 2 * PIECES ? 2 * PIECES : t) - 1 : 0);       // + the calling thread
+  }
+  G.film_pool->run(2 * PIECES, [&](size_t j) {
+    const size_t k = j / 2;
+    if (hipEventSynchronize(film_ev[k]) != hipSuccess) { bad.store(1); return; }
+    const size_t mid = (cut[k] + (cut[k + 1] - cut[k]) / 2) & ~(size_t) 3;
+    const size_t lo = (j & 1) ? (mid > cut[k] ? mid : cut[k]) : cut[k], hi = (j & 1) ? cut[k + 1] : (mid > cut[k] ? mid : cut[k]);
+    if (hi > lo) widen_film(h_film + lo, hi - lo, rgb_out + 3 * lo);
+  });
   e = hipStreamSynchronize(G.stream);
   if (e != hipSuccess || bad.load()) return fail(MIRT_E_DEVICE, std::string("tonemap: ") + hipGetErrorString(e));
   return MIRT_OK;

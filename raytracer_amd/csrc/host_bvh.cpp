@@ -11,6 +11,8 @@
 #include <exception>
 #include <limits>
 #include <stdexcept>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 namespace mirt {
@@ -47,6 +49,81 @@ void parallel_for(size_t n, const std::function<void(size_t, size_t)> &body, siz
   }
   for (auto &x: th) x.join();
   for (auto &x: err) if (x) std::rethrow_exception(x);
+}
+
+struct WorkerPool::Impl {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable wake, done;
+  const std::function<void(size_t)> *job = nullptr;
+  size_t n_jobs = 0, finished = 0;
+  std::atomic<size_t> next{0};
+  unsigned busy = 0;            // workers inside the job loop of the current run
+  uint64_t epoch = 0;
+  bool stop = false;
+
+  void drain(const std::function<void(size_t)> &f, size_t n) {      // take jobs until none is left; returns how many this thread ran
+    size_t ran = 0;
+    for (size_t j = next.fetch_add(1); j < n; j = next.fetch_add(1)) {
+      try { f(j); } catch (...) {}                                    // (jobs report through their own state)
+      ran++;
+    }
+    std::lock_guard<std::mutex> lk(m);
+    finished += ran;
+  }
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(size_t)> *f;
+      size_t n;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        wake.wait(lk, [&] { return stop || epoch != seen; });
+        if (stop) return;
+        seen = epoch;
+        f = job;
+        n = n_jobs;
+        busy++;
+      }
+      drain(*f, n);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        busy--;
+      }
+      done.notify_all();
+    }
+  }
+};
+
+WorkerPool::WorkerPool(unsigned workers) : impl(new Impl) {
+  for (unsigned k = 0; k < workers; k++) impl->th.emplace_back([this] { impl->worker(); });
+}
+WorkerPool::~WorkerPool() {
+  {
+    std::lock_guard<std::mutex> lk(impl->m);
+    impl->stop = true;
+  }
+  impl->wake.notify_all();
+  for (auto &t: impl->th) t.join();
+  delete impl;
+}
+unsigned WorkerPool::workers() const { return (unsigned) impl->th.size(); }
+void WorkerPool::run(size_t n_jobs, const std::function<void(size_t)> &job) {
+  if (n_jobs == 0) return;
+  {
+    std::lock_guard<std::mutex> lk(impl->m);
+    impl->job = &job;
+    impl->n_jobs = n_jobs;
+    impl->finished = 0;
+    impl->next.store(0);
+    impl->epoch++;
+  }
+  impl->wake.notify_all();
+  impl->drain(job, n_jobs);
+  // all jobs done AND no worker still inside this run's loop (one that woke late must not meet the next run's counter)
+  std::unique_lock<std::mutex> lk(impl->m);
+  impl->done.wait(lk, [&] { return impl->finished == n_jobs && impl->busy == 0; });
+  impl->job = nullptr;
 }
 
 namespace {

@@ -20,6 +20,23 @@ namespace mirt {
 unsigned host_threads();
 void parallel_for(size_t n, const std::function<void(size_t, size_t)> &body, size_t min_chunk = 8192);
 
+// Host threads that outlive a call, for work that recurs every frame (the film's widening, capi.hip mirt_tonemap): starting
+// and joining 16 std::threads costs ~0.4 ms, as much as the work they are started for.  run() hands jobs 0 .. n_jobs - 1 to the
+// workers and the calling thread and returns when all are done.  One run() at a time per pool.
+class WorkerPool {
+ public:
+  explicit WorkerPool(unsigned workers);
+  ~WorkerPool();
+  WorkerPool(const WorkerPool &) = delete;
+  WorkerPool &operator=(const WorkerPool &) = delete;
+  void run(size_t n_jobs, const std::function<void(size_t)> &job);
+  unsigned workers() const;
+
+ private:
+  struct Impl;
+  Impl *impl;
+};
+
 struct Node2 {            // = BVHNodeOpt (bvh/bvh.cuh:12-30), 32 bytes
   float minp[3];
   float maxp[3];

@@ -1,0 +1,38 @@
+// CPU check of two host-side helpers of libmirt that need no GPU (tests/test_host.py compiles this against
+// raytracer_amd/csrc/host_bvh.cpp and host_film.cpp): WorkerPool runs every job exactly once, run after run, with more and
+// with fewer jobs than threads; widen_film equals the scalar definition for every length / alignment.
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "host_bvh.hpp"
+#include "host_film.hpp"
+
+int main() {
+  for (unsigned workers : {0u, 1u, 3u, 15u}) {
+    mirt::WorkerPool pool(workers);
+    for (int round = 0; round < 300; round++) {
+      const size_t n = (size_t) (round % 37);
+      std::vector<std::atomic<int>> hits(n);
+      for (auto &h : hits) h.store(0);
+      pool.run(n, [&](size_t j) { hits[j].fetch_add(1); });
+      for (size_t j = 0; j < n; j++)
+        if (hits[j].load() != 1) { printf("pool(%u) round %d: job %zu ran %d times\n", workers, round, j, hits[j].load()); return 1; }
+    }
+  }
+  for (size_t n : {0ul, 1ul, 3ul, 4ul, 5ul, 7ul, 1000ul, 259200ul})
+    for (int off = 0; off < 4; off++) {
+      std::vector<uint32_t> in(n + 8);
+      for (size_t i = 0; i < n + 8; i++) in[i] = (uint32_t) (i * 2654435761u) & 0xFFFFFFu;
+      std::vector<int32_t> out(3 * n + 16, -7), want(3 * n + 16, -7);
+      for (size_t i = 0; i < n; i++) {
+        const uint32_t v = in[i + 1];
+        want[off + 3 * i] = v & 255; want[off + 3 * i + 1] = (v >> 8) & 255; want[off + 3 * i + 2] = (v >> 16) & 255;
+      }
+      mirt::widen_film(in.data() + 1, n, out.data() + off);
+      if (out != want) { printf("widen_film mismatch n=%zu off=%d\n", n, off); return 1; }
+    }
+  printf("ok\n");
+  return 0;
+}

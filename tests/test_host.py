@@ -242,3 +242,20 @@ int main() {
 ''')
     r = _gxx(["-fsyntax-only", str(src)])
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_worker_pool_and_film_widening_native(tmp_path):
+    """Host helpers of libmirt that need no GPU (tests/native/host_pool_check.cpp against the library's own sources): the
+    persistent worker pool runs every job exactly once, run after run; the vectorised film widening equals the scalar rule
+    `r | g << 8 | b << 16 -> three ints` (util/image.cuh:9-48 layout) for every length and alignment."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "raytracer_amd", "csrc")
+    exe = str(tmp_path / "host_pool_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", csrc, "-o", exe,
+                           os.path.join(root, "tests", "native", "host_pool_check.cpp"),
+                           os.path.join(csrc, "host_bvh.cpp"), os.path.join(csrc, "host_film.cpp")])
+    for _ in range(5):
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
