@@ -29,9 +29,9 @@ with open(sys.argv[2], newline="") as fh:
         if k in NAMES:
             dur[NAMES[k]] = (float(r["TotalDurationNs"]) * 1e-9, int(r["Calls"]))
 rays = json.loads(sys.argv[3].replace("'", '"')) if len(sys.argv) > 3 else {}
-out = {"command": "tools/r3_pmc.sh (tools/pmc_run.sh 64 1920 1080 8: one rocprofv3 --pmc pass per counter set over tools/prof_frame.py; "
+out = {"command": "tools/r3_pmc.sh (tools/pmc_run.sh 64 1920 1080 8 64: one rocprofv3 --pmc pass per counter set over tools/prof_frame.py; "
                   "MIRT_SERIAL=1 rocprofv3 --kernel-trace --stats over the same program for durations alone)",
-       "configuration": {"workload": "conference*", "width": 1920, "height": 1080, "spp": 64, "depth": 8, "streams": 8, "traversal": 0,
+       "configuration": {"workload": "conference*", "width": 1920, "height": 1080, "spp": 64, "depth": 8, "streams": 8, "shares": 64, "traversal": 0,
                          "n_gpus": 1},
        "frame": rays, "units": "SQ_* in quad-cycles summed over waves; GRBM_GUI_ACTIVE summed over the 8 XCDs", "kernels": {}}
 for name, c in pmc.items():
