@@ -538,6 +538,54 @@ static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const u
   return MIRT_OK;
 }
 
+}  // extern "C"
+
+namespace mirt {
+// A replica of `src` on the calling thread's device (mirt_group_set_scene: the first member builds the scene - host trees,
+// packed records, uploads - the others copy its device buffers instead of repeating the host build N times at once).  `src`
+// may live on another device: the copies are plain unified-address copies.  Nothing may be using `src` meanwhile.
+int scene_clone(const mirt_scene *src, mirt_scene **out) {
+  if (!G.ready) return fail(MIRT_E_STATE, "mirt_init() has not been called");
+  if (!src || !out) return fail(MIRT_E_ARG, "null argument");
+  *out = nullptr;
+  mirt_scene *s = nullptr;
+  try {
+    s = new mirt_scene();
+    s->bvh = src->bvh;                                   // host-side arrays behind mirt_scene_info / _bvh2 / _own_tree
+  } catch (const std::exception &ex) {
+    delete s;
+    return fail(MIRT_E_LIMIT, std::string("scene replica failed: ") + ex.what());
+  }
+  s->n_tris = src->n_tris; s->n_mats = src->n_mats; s->n_lights = src->n_lights;
+  s->has_microfacet = src->has_microfacet; s->has_spheres = src->has_spheres; s->sph_rmin = src->sph_rmin;
+  s->fast_ok = src->fast_ok; s->own_builder = src->own_builder; s->n_nodes8 = src->n_nodes8; s->depth8 = src->depth8;
+  memcpy(s->build_ms, src->build_ms, sizeof s->build_ms);
+  s->ovf_depth = src->ovf_depth;
+  s->device = G.device;
+  s->trace_threads = (uint32_t) (G.n_cu * G.blocks_per_cu * TRACE_BLOCK);
+  const DevBuf mirt_scene::*data[] = {&mirt_scene::nodes4, &mirt_scene::nodes2, &mirt_scene::tris, &mirt_scene::tri_nrm, &mirt_scene::mats,
+                                      &mirt_scene::lights, &mirt_scene::big, &mirt_scene::trisf, &mirt_scene::nodes8q, &mirt_scene::verts};
+  bool ok = true;
+  for (auto m: data) {
+    const DevBuf &from = src->*m;
+    DevBuf &to = const_cast<DevBuf &>(s->*m);
+    if (!from.p || !from.bytes) continue;
+    ok = ok && to.ensure(from.bytes) == hipSuccess && hipMemcpy(to.p, from.p, from.bytes, hipMemcpyDefault) == hipSuccess;
+  }
+  ok = ok && G.ovf.ensure(2 * MAX_PIPES * (size_t) s->ovf_depth * s->trace_threads * sizeof(uint2)) == hipSuccess;
+  if (!ok) {
+    const int rc = fail(MIRT_E_DEVICE, std::string("scene replica failed: ") + hipGetErrorString(hipGetLastError()));
+    s->release_all();
+    delete s;
+    return rc;
+  }
+  *out = s;
+  return MIRT_OK;
+}
+}  // namespace mirt
+
+extern "C" {
+
 void mirt_scene_destroy(mirt_scene *s) {
   if (!s) return;
   if (G.ready) (void) hipDeviceSynchronize();                            // every pipe and side stream

@@ -24,6 +24,7 @@
 namespace mirt {
 hipStream_t current_stream();                     // capi.hip: the calling thread's main stream
 int set_error(int code, const std::string &msg);  // capi.hip: sets mirt_last_error() of the calling thread
+int scene_clone(const mirt_scene *src, mirt_scene **out);   // capi.hip: a replica of a scene on the calling thread's device
 }  // namespace mirt
 
 namespace {
@@ -209,11 +210,23 @@ int mirt_group_set_scene(mirt_group *g, const float *tri_pos, const float *tri_n
                          uint32_t n_prims, const mirt_bsdf *mats, uint32_t n_mats, const mirt_light *lights, uint32_t n_lights,
                          uint32_t leaf_size, const mirt_build_options *build) {
   if (!g) return mirt::set_error(MIRT_E_ARG, "null group");
-  return g->run([&](Member &mb) {
+  // The first member builds the scene (the reference's BVH2, its fold, the SAH tree: host threads, then the uploads); the others
+  // then replicate its device buffers.  (Every member used to run the whole host build at the same time: N times the work on N
+  // times oversubscribed cores.)
+  int rc = g->run([&](Member &mb) {
     if (mb.scene) mirt_scene_destroy(mb.scene);
     mb.scene = nullptr;
-    return mirt_scene_create_opts(tri_pos, tri_nrm, tri_mat, prim_type, n_prims, mats, n_mats, lights, n_lights, leaf_size, build,
-                                  &mb.scene);
+    if (mb.index != 0) return (int) MIRT_OK;
+    const int r = mirt_scene_create_opts(tri_pos, tri_nrm, tri_mat, prim_type, n_prims, mats, n_mats, lights, n_lights, leaf_size, build,
+                                         &mb.scene);
+    if (r == MIRT_OK && hipDeviceSynchronize() != hipSuccess) return mirt::set_error(MIRT_E_DEVICE, "device error after the scene build");
+    return r;
+  });
+  if (rc != MIRT_OK || g->members.size() < 2) return rc;
+  const mirt_scene *first = g->members[0]->scene;
+  return g->run([&](Member &mb) {
+    if (mb.index == 0) return (int) MIRT_OK;
+    return mirt::scene_clone(first, &mb.scene);
   });
 }
 
