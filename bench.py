@@ -258,7 +258,7 @@ def pick_shares(spp, want, streams):
     off) when that is not more than the sample streams.  want = 0, the default: one share per sample up to 64 samples per
     pixel, and no pool above that - a slot that renders 32 or more samples in sequence is balanced by their number, and the
     pool's item fetches in k_logic only cost (buddha* 256 spp: 304 ms without, 312 ms with; sportsCar* 4K 1024 spp: 6.52 s /
-    6.63 s; conference* 64 spp: 118.8 / 116.0 ms; tools/pool_ab.sh, gpurun_out/buddha_pool_probe.txt)."""
+    6.63 s; conference* 64 spp: 118.8 / 116.0 ms; tools/pool_ab.sh, profiles/r3b_buddha_pool_probe.txt)."""
     if want == 1 or spp < 2 or (want == 0 and spp > 64):
         return 0
     cap = min(spp, want if want > 0 else 64)
