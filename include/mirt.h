@@ -267,7 +267,7 @@ int mirt_trace_static(mirt_scene *scene, const float *rays_dev, uint32_t n, int 
  * switched on; needs S >= n); MIRT_PARTITION_TILE: interleaved 8x8 tiles, bit-identical to one GPU - then ONE sum of the
  * float4 accumulation buffers onto member 0 (RCCL ncclReduce over xGMI when every member has a GPU of its own - librccl is
  * loaded at run time, only then; members sharing a GPU are added by a kernel, in member order) and the film as mirt_render
- * returns it.  devices[]: HIP device index per member; an index may repeat (logical partitions of one GPU).  stats: ray
+ * returns it (opts->shares, if set, is reduced per member to a divisor of the samples that member renders).  devices[]: HIP device index per member; an index may repeat (logical partitions of one GPU).  stats: ray
  * counts summed over the members, times = the slowest member's.  opts: as mirt_render, tile_* / sample_* must be zero. */
 typedef struct mirt_group mirt_group;
 #define MIRT_PARTITION_SPP 0

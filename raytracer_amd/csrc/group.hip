@@ -266,6 +266,13 @@ int mirt_group_render(mirt_group *g, const mirt_camera *camera, const mirt_param
       o.sample_begin = (uint32_t) mb.index * per;
       o.sample_count = (uint32_t) mb.index + 1 < n ? per : params->samples_per_pixel - per * (n - 1);
     }
+    if (o.shares > 1) {
+      // share pool: the shares must divide the samples THIS member renders - take the largest common divisor of what the
+      // caller asked for and the member's sample count (a result not above `streams` switches the pool off, mirt.h)
+      uint32_t a = o.shares, b = o.sample_count ? o.sample_count : params->samples_per_pixel;
+      while (b) { const uint32_t t = a % b; a = b; b = t; }
+      o.shares = a;
+    }
     return mirt_render_accum(mb.scene, camera, params, &o, width, height, mb.accum, &mb.stats);
   });
   if (rc) return rc;

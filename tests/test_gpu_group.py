@@ -31,6 +31,16 @@ def test_logical_partitions_equal_the_single_context_frame(mirt):
         assert (img == want_counter).mean() >= 0.999                                   # same samples, re-associated sums
         assert (g.last["closest_rays"], g.last["shadow_rays"], g.last["paths"]) == counts
         g.close()
+    # share pool through a group: every member reduces `shares` to a divisor of its own sample count (3 members, 6 spp: 2
+    # samples each; tile partition: 6) - the films equal those of the same partitions rendered with sample streams
+    for n, part in ((3, "spp"), (2, "tile")):
+        g = mirt.Group([0] * n)
+        g.set_scene(sc)
+        pool = g.render(w, h, partition=part, rng_mode=1, seed=9, streams=1, shares=6, **kw)
+        want = g.render(w, h, partition=part, rng_mode=1, seed=9, streams=2 if part == "spp" else 6, **kw)
+        assert (pool == want).all()
+        assert (g.last["closest_rays"], g.last["shadow_rays"], g.last["paths"]) == counts
+        g.close()
     g = mirt.Group([0, 0])
     with pytest.raises(mirt.MirtError) as e:
         g.render(8, 8)
