@@ -47,3 +47,17 @@ def test_gpus_1_runs_in_process():
 def test_world_size_must_equal_gpus():
     p = _run(["--gpus", "2", "--backend", "gloo"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, expect_ok=False)
     assert p.returncode != 0 and "must agree" in p.stderr
+
+
+def test_share_pool_policy_of_the_bench():
+    """bench.pick_shares: one share per sample up to 64 samples per pixel and rank (a divisor of the rank's sample count),
+    off above that, off when it would not exceed the sample streams, explicit requests rounded down to a divisor."""
+    import bench
+
+    assert bench.pick_shares(64, 0, 8) == 64 and bench.pick_shares(8, 0, 4) == 8 and bench.pick_shares(32, 0, 4) == 32
+    assert bench.pick_shares(256, 0, 8) == 0 and bench.pick_shares(1024, 0, 8) == 0          # balanced by their sample count
+    assert bench.pick_shares(8, 0, 8) == 0 and bench.pick_shares(64, 1, 8) == 0 and bench.pick_shares(1, 0, 1) == 0
+    assert bench.pick_shares(100, 64, 8) == 50 and bench.pick_shares(256, 64, 8) == 64 and bench.pick_shares(13, 0, 4) == 13
+    for spp in range(2, 70):
+        w = bench.pick_shares(spp, 0, 4)
+        assert w == 0 or (spp % w == 0 and 4 < w <= 64)
