@@ -1,7 +1,9 @@
 // The reference's application (apps/app.cu:8-38) against the MI355X render path: 500 000 emissive particles thrown from the
 // origin, 80 frames of physics + scene rebuild + render + BMP, written against the same host API (PhysicsSystem, Generator,
 // PathTracer).  The reference takes no arguments; with none this runs its exact configuration.  Optional:
-//   app [--frames 80] [--particles 500000] [--w 800 --h 600] [--spp 100] [--prefix sim] [--no-save] [--host-build]
+//   app [--frames 80] [--particles 500000] [--w 800 --h 600] [--spp 100] [--prefix sim] [--no-save] [--host-build] [--fast]
+// --fast (an extension, not the reference's image): counter-based RNG, 8 paths per pixel in flight and a share pool of one-sample
+// shares (PathTracer::options) instead of the reference's one sequential xorshift stream per pixel; the adaptive stop is off then.
 // The traversal's own tree is built on the GPU (PLOC): the scene is rebuilt every frame.
 #include <chrono>
 #include <cstdlib>
@@ -11,7 +13,7 @@
 
 int main(int argc, char **argv) {
   uint frames = 80, particles = 500000, w = 800, h = 600, spp = 100, builder = 2;
-  bool save = true;
+  bool save = true, fast = false;
   std::string prefix = "sim";
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
@@ -24,6 +26,7 @@ int main(int argc, char **argv) {
     else if (a == "--prefix") prefix = next();
     else if (a == "--no-save") save = false;
     else if (a == "--host-build") builder = 0;
+    else if (a == "--fast") fast = true;
   }
   printf("Starting program\n");
 
@@ -43,6 +46,11 @@ int main(int argc, char **argv) {
 
     PathTracer pathtracer({spp, 1, 64, 0.05f, 8, 4});
     pathtracer.build_options.own_tree_builder = builder;
+    if (fast) {
+      pathtracer.options.rng_mode = 1;
+      pathtracer.options.streams = spp >= 8 ? 8 : 1;
+      pathtracer.options.shares = spp;                     // one share per sample (ignored unless it exceeds the streams)
+    }
     pathtracer.set_camera({0, 175, -300}, {0, 20, 0}, {0, 1, 0}, 42, (float) (42 * (int) h / (int) w), 0, INFINITY, 0, 0);
     pathtracer.resize(w, h);
     pathtracer.set_scene(primitives, lights);
