@@ -81,6 +81,9 @@ struct WorkerPool::Impl {
         wake.wait(lk, [&] { return stop || epoch != seen; });
         if (stop) return;
         seen = epoch;
+        // a worker that wakes after its run() has returned (the caller did all the jobs itself) finds no job: it must not
+        // pair that run's job count with the claim counter of the next run
+        if (job == nullptr) continue;
         f = job;
         n = n_jobs;
         busy++;
