@@ -26,6 +26,7 @@ else
   run $S/render_app $T/c.bmp --w 96 --h 54 --spp 4 --depth 5 --rng 1 --parts 2 --partition spp
   run $S/particle_app --frames 2 --particles 20000 --w 160 --h 120 --spp 4 --prefix $T/p_
   run $S/particle_app --frames 2 --particles 20000 --w 160 --h 120 --spp 4 --prefix $T/q_ --host-build
+  run $S/particle_app --frames 2 --particles 20000 --w 160 --h 120 --spp 16 --prefix $T/r_ --fast
   cmp $T/a.bmp $T/b.bmp || { echo "films differ"; exit 1; }
   cmp $T/p_1.bmp $T/q_1.bmp || { echo "particle films differ"; exit 1; }
   if grep -E "ERROR: AddressSanitizer|runtime error:" $T/all; then grep -E -A12 "ERROR: AddressSanitizer|runtime error:" $T/all | head -60; exit 1; fi
