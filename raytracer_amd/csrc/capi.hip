@@ -712,16 +712,16 @@ int ensure_work(mirt_scene *s, uint32_t n_slots, uint32_t K) {
   if (int rc = ensure_overflow_region(s)) return rc;
   const size_t n = n_slots ? n_slots : 64, kn = (size_t) (K ? K : 1) * n;
   HIPCHK(s->st.ensure(n * 16));
-  HIPCHK(s->mask.ensure(n * 16));
+  HIPCHK(s->mask.ensure(n * sizeof(rec3)));
   HIPCHK(s->total.ensure(n * 16));
   HIPCHK(s->accum.ensure(n * 16));
-  HIPCHK(s->dmask.ensure(n * 16));
+  HIPCHK(s->dmask.ensure(n * sizeof(rec3)));
   HIPCHK(s->ray_o.ensure(n * 16));
   HIPCHK(s->ray_d.ensure(n * 16));
   HIPCHK(s->hit.ensure(n * 16));
-  HIPCHK(s->sh_o.ensure(kn * 16));
+  HIPCHK(s->sh_o.ensure((MIRT_SHARED_ORIGIN ? n : kn) * 16));     // one origin per slot (mirt_trace: per ray, K = 1)
   HIPCHK(s->sh_d.ensure(kn * 16));
-  HIPCHK(s->sh_c.ensure(kn * 16));
+  HIPCHK(s->sh_c.ensure(kn * sizeof(rec3)));
   HIPCHK(s->sh_occ.ensure(kn * 4));
   HIPCHK(s->ext_queue.ensure(n * 4));
   HIPCHK(s->sh_queue.ensure(kn * 4));
@@ -776,11 +776,14 @@ TraceArgs closest_args(mirt_scene *s, uint32_t n_slots, uint32_t traversal, int 
   t.count_stat = rs + 4;
   return t;
 }
-TraceArgs shadow_args(mirt_scene *s, uint32_t traversal, int pipe = 0, size_t koff = 0, int par = 0) {
+// (o_slots != 0: the shadow rays of a render - one origin per slot, at sh_o + off, entry k * o_slots + slot; 0: mirt_trace's
+// occlusion rays, one origin per ray)
+TraceArgs shadow_args(mirt_scene *s, uint32_t traversal, int pipe = 0, size_t koff = 0, int par = 0, size_t off = 0, uint32_t o_slots = 0) {
   TraceArgs t = common_args(s, traversal);
   uint32_t *ctrl = s->ctrl.as<uint32_t>() + (size_t) (CTRL_BLOCKS * pipe + par) * CTRL_WORDS;
   unsigned long long *rs = s->ray_stats.as<unsigned long long>() + (size_t) pipe * 16;
-  t.ray_o = s->sh_o.as<float4>() + koff;
+  t.ray_o = s->sh_o.as<float4>() + (o_slots ? off : koff);
+  t.o_slots = o_slots;
   t.ray_d = s->sh_d.as<float4>() + koff;
   t.queue = s->sh_queue.as<uint32_t>() + koff;
   t.qcount = ctrl + CTRL_QCOUNT;
@@ -895,10 +898,10 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   a.adaptive = sliced ? 0 : 1;
   a.glass_int_abs = o.glass_int_abs; a.n_lights = s->n_lights; a.tol = prm->max_tolerance;
   a.cam = to_device_camera(*camera);
-  a.st = s->st.as<uint4>(); a.mask = s->mask.as<float4>(); a.total = s->total.as<float4>();
-  a.accum = s->accum.as<float4>(); a.dmask = s->dmask.as<float4>();
+  a.st = s->st.as<uint4>(); a.mask = s->mask.as<rec3>(); a.total = s->total.as<float4>();
+  a.accum = s->accum.as<float4>(); a.dmask = s->dmask.as<rec3>();
   a.ray_o = s->ray_o.as<float4>(); a.ray_d = s->ray_d.as<float4>(); a.hit = s->hit.as<float4>();
-  a.sh_o = s->sh_o.as<float4>(); a.sh_d = s->sh_d.as<float4>(); a.sh_c = s->sh_c.as<float4>();
+  a.sh_o = s->sh_o.as<float4>(); a.sh_d = s->sh_d.as<float4>(); a.sh_c = s->sh_c.as<rec3>();
   a.sh_occ = s->sh_occ.as<uint32_t>();
   a.ext_queue = s->ext_queue.as<uint32_t>(); a.sh_queue = s->sh_queue.as<uint32_t>();
   uint32_t *ctrl = s->ctrl.as<uint32_t>();
@@ -977,13 +980,13 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
     pa.stream_first = s_first;
     pa.st += off; pa.mask += off; pa.total += off; pa.accum += off; pa.dmask += off;
     pa.ray_o += off; pa.ray_d += off; pa.hit += off;
-    pa.sh_o += koff; pa.sh_d += koff; pa.sh_c += koff; pa.sh_occ += koff;
+    pa.sh_o += MIRT_SHARED_ORIGIN ? off : koff; pa.sh_d += koff; pa.sh_c += koff; pa.sh_occ += koff;
     pa.ext_queue += off; pa.sh_queue += koff; pa.mf_queue += off;
     pa.ray_stats = a.ray_stats + (size_t) p * 16;
     for (int b = 0; b < CTRL_BLOCKS; b++) {
       pp.ctrl[b] = ctrl + (size_t) (CTRL_BLOCKS * p + b) * CTRL_WORDS;
       pp.tc[b] = closest_args(s, pa.n_slots, o.traversal, p, off, b);
-      pp.ts[b] = shadow_args(s, o.traversal, p, koff, b);
+      pp.ts[b] = shadow_args(s, o.traversal, p, koff, b, off, MIRT_SHARED_ORIGIN ? pa.n_slots : 0u);
     }
   }
   uint32_t iters = 0;
@@ -1255,7 +1258,7 @@ int mirt_primary_hits(mirt_scene *s, const mirt_camera *camera, const mirt_optio
   a.tiles_x = part.tiles_x; a.tiles_y = part.tiles_y; a.tile_rank = 0; a.tile_world = 1;
   a.rng_mode = o.rng_mode; a.seed = o.seed; a.spp = 1; a.batch = 2;
   a.cam = to_device_camera(*camera);
-  a.st = s->st.as<uint4>(); a.mask = s->mask.as<float4>(); a.total = s->total.as<float4>();
+  a.st = s->st.as<uint4>(); a.mask = s->mask.as<rec3>(); a.total = s->total.as<float4>();
   a.accum = s->accum.as<float4>(); a.ray_o = s->ray_o.as<float4>(); a.ray_d = s->ray_d.as<float4>();
   a.hit = s->hit.as<float4>(); a.ext_queue = s->ext_queue.as<uint32_t>();
   uint32_t *ctrl = s->ctrl.as<uint32_t>();

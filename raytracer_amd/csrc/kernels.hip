@@ -129,7 +129,7 @@ __global__ void k_init(RenderArgs a) {
   if (s >= a.n_slots) return;
   const uint4 st = initial_state(a, s);
   a.st[s] = st;
-  a.mask[s] = make_float4(1, 1, 1, 0);
+  a.mask[s] = mk_rec3(1, 1, 1);
   a.total[s] = make_float4(0, 0, 0, 0);
   a.accum[s] = make_float4(0, 0, 0, 0);
 }
@@ -244,7 +244,8 @@ constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
 
 // What k_logic requests together with a slot's state record, before it knows what the slot needs (MIRT_LOGIC_EAGER).
 struct SlotEager {
-  float4 h, tot4, dm, sc0, sc1;
+  float4 h, tot4;
+  rec3 dm, sc0, sc1;
   uint32_t occ0, occ1;
 };
 template<bool MF>
@@ -260,7 +261,8 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t 
   const float4 tot4 = first ? make_float4(0, 0, 0, 0)                    // (a frame's first iteration: nothing to read yet)
                             : ((MIRT_LOGIC_EAGER >= 1 && eager) ? eager->tot4 : a0.total[s]);
   float4 acc4 = make_float4(0, 0, 0, 0);              // loaded when a sample is finished (once in a few iterations)
-  float4 m4 = make_float4(0, 0, 0, 0), ro = m4, rd = m4, dm = m4, sc0 = m4, sc1 = m4;
+  float4 ro = make_float4(0, 0, 0, 0), rd = ro;
+  rec3 m4 = mk_rec3(0, 0, 0), dm = m4, sc0 = m4, sc1 = m4;
   uint32_t occ0 = 1, occ1 = 1;
   if (n_shadow) {
     if (MIRT_LOGIC_EAGER >= 2 && eager) {
@@ -341,7 +343,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t 
     for (uint32_t k = 2; k < n_shadow; k++) {
       size_t e = (size_t) k * a.n_slots + s;
       if (a.sh_occ[e] == 0) {
-        float4 cc = a.sh_c[e];
+        rec3 cc = a.sh_c[e];
         color = vadd(color, mk(cc.x, cc.y, cc.z));
       }
     }
@@ -463,14 +465,19 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t 
                 em.cull |= 1u << k;
                 continue;
               }
+#if !MIRT_SHARED_ORIGIN
               a.sh_o[e] = make_float4(so.x, so.y, so.z, MIRT_EPS);
+#endif
               a.sh_d[e] = make_float4(to_light.x, to_light.y, to_light.z, dist - MIRT_EPS);
-              a.sh_c[e] = make_float4(contrib.x, contrib.y, contrib.z, 0);
+              a.sh_c[e] = mk_rec3(contrib.x, contrib.y, contrib.z);
             }
           }
           n_shadow = k;
           em.nsh = k;
-          a.dmask[s] = make_float4(mask.x, mask.y, mask.z, 0);
+#if MIRT_SHARED_ORIGIN
+          a.sh_o[s] = make_float4(so.x, so.y, so.z, MIRT_EPS);         // the one origin of this hit's shadow rays
+#endif
+          a.dmask[s] = mk_rec3(mask.x, mask.y, mask.z);
         }
 
         float cpdf = smax(mask.x, smax(mask.y, mask.z));                // raytracer.cuh:71
@@ -497,7 +504,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t 
       }
 
       if (!path_ends) {
-        a.mask[s] = make_float4(mask.x, mask.y, mask.z, 0);
+        a.mask[s] = mk_rec3(mask.x, mask.y, mask.z);
         emit_extension(a, s, next, false, em);
       } else {
         c.flags &= ~F_HAS_RAY;
@@ -559,7 +566,7 @@ __device__ __forceinline__ void slot_commit(const RenderArgs &a0, const uint32_t
       }
       c.sample_base = a.sample_begin + first;
       c.rng.key = ctr_key(py * a.width + px, a.seed);
-      a.mask[s] = make_float4(1, 1, 1, 0);
+      a.mask[s] = mk_rec3(1, 1, 1);
       generate_camera_ray(a, s, px, py, c, 1, em);
     } else if (!(c.flags & F_PENDING)) {
       T.finished = true;                               // nothing left for this slot
@@ -569,7 +576,7 @@ __device__ __forceinline__ void slot_commit(const RenderArgs &a0, const uint32_t
     bool valid;
     item_share(a, T.item, share, pslot, first, count);
     pslot_to_pixel(a, pslot, px, py, valid);
-    a.mask[s] = make_float4(1, 1, 1, 0);
+    a.mask[s] = mk_rec3(1, 1, 1);
     generate_camera_ray(a, s, px, py, c, T.cam_n, em);
   }
   if (T.finished) {
@@ -636,7 +643,7 @@ __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
         SlotEager eg;
         eg.h = a.hit[s];
         eg.tot4 = a.total[s];
-        eg.dm = eg.sc0 = eg.sc1 = make_float4(0, 0, 0, 0);
+        eg.dm = eg.sc0 = eg.sc1 = mk_rec3(0, 0, 0);
         eg.occ0 = eg.occ1 = 1;
 #if MIRT_LOGIC_EAGER >= 2
         eg.dm = a.dmask[s];
@@ -740,8 +747,16 @@ __device__ __forceinline__ bool finite3(V3 v) {
   return (fabsf(v.x) < MIRT_INF) && (fabsf(v.y) < MIRT_INF) && (fabsf(v.z) < MIRT_INF);
 }
 
+// SHARED: the launch may carry the shadow rays of a render (TraceArgs::o_slots).  Only the occlusion kernels are compiled with
+// it: in the closest-hit kernel the few extra instructions moved the register allocation from 72 to 77 VGPRs (one resident wave less).
+template<bool SHARED>
 __device__ __forceinline__ void load_ray(const TraceArgs &a, uint32_t id, LaneRay &r) {
-  const float4 ro = a.ray_o[id], rd = a.ray_d[id];
+  uint32_t oi = id;
+  if (SHARED && a.o_slots && oi >= a.o_slots) {                 // shadow rays of a render: entry k * n_slots + slot starts at the slot's origin
+    oi -= a.o_slots;
+    if (oi >= a.o_slots) oi %= a.o_slots;
+  }
+  const float4 ro = a.ray_o[oi], rd = a.ray_d[id];
   r.o = mk(ro.x, ro.y, ro.z);
   const V3 d_arg = mk(rd.x, rd.y, rd.z);
   r.d = vunit(d_arg);                 // ray.cuh:20
@@ -912,7 +927,7 @@ __device__ __forceinline__ bool slab_exact(const float *lo, const float *hi, con
 template<bool ANY>
 __device__ __forceinline__ void walk_reference_lane(const TraceArgs &a, uint32_t id) {
   LaneRay r;
-  load_ray(a, id, r);
+  load_ray<ANY>(a, id, r);
   uint32_t stack[BVH2_STACK];
   uint32_t sp = 0;
   stack[sp++] = 0;
@@ -988,7 +1003,7 @@ __global__ void __launch_bounds__(256) k_redo(TraceArgs a) {
   for (uint32_t w = wave; w < total; w += n_waves) {
     const uint32_t id = a.redo_queue[w];
     LaneRay r;
-    load_ray(a, id, r);
+    load_ray<ANY>(a, id, r);
     uint32_t sp = 0;
     stack[sp++] = 0;
     bool found = false;
@@ -1117,7 +1132,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
           const uint32_t w = w_next + lane_rank(need);
           const uint32_t id = (w < w_end) ? ((w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)]) : QUEUE_SKIP;
           if (id != QUEUE_SKIP) {                          // (QUEUE_SKIP in the queue: a culled shadow ray)
-            load_ray(a, id, r);
+            load_ray<ANY>(a, id, r);
             // Slab and hit arithmetic stays finite for these rays; anything else (zero direction components -> 0 * inf,
             // non-finite origins, NaN bounds) makes the reference's result depend on its visiting order: defer to k_trace2.
             bool regular = finite3(r.o) && finite3(r.d) && finite3(r.inv) && (r.best_t == r.best_t) &&
@@ -1445,7 +1460,7 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
           const uint32_t w = w_next + lane_rank(need);
           const uint32_t id = (w < w_end) ? ((w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)]) : QUEUE_SKIP;
           if (id != QUEUE_SKIP) {                          // (QUEUE_SKIP in the queue: a culled shadow ray)
-            load_ray(a, id, r);
+            load_ray<ANY>(a, id, r);
             // Rays the shortcut arithmetic is not meant for take the reference walk: non-finite origin / direction /
             // reciprocal (the reference's result then depends on its visiting order), a direction almost parallel to an
             // axis plane ((p - o) * inv would lose all precision), and ctor directions that are not unit length (the

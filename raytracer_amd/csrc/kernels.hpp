@@ -6,7 +6,22 @@
 #include "host_bvh.hpp"
 #include "shade.hpp"
 
+#ifndef MIRT_REC12
+#define MIRT_REC12 1          // path masks and shadow contributions as 12-byte records (0: 16-byte records with a pad word)
+#endif
+#ifndef MIRT_SHARED_ORIGIN
+#define MIRT_SHARED_ORIGIN 1  // the shadow rays of a hit share one origin record per slot (0: one origin per shadow ray)
+#endif
+
 namespace mirt {
+
+#if MIRT_REC12
+typedef float3 rec3;
+__host__ __device__ inline rec3 mk_rec3(float x, float y, float z) { return make_float3(x, y, z); }
+#else
+typedef float4 rec3;
+__host__ __device__ inline rec3 mk_rec3(float x, float y, float z) { return make_float4(x, y, z, 0.f); }
+#endif
 
 constexpr int TRACE_BLOCK = 256;
 #ifndef MIRT_LDS_STACK
@@ -36,12 +51,13 @@ struct RenderArgs {
   DCamera cam;
   // per-slot path state (SoA, 16-byte records)
   uint4 *st;            // rng state | sample index | flags + shadow count << 8 | bounce index
-  float4 *mask;         // color_mask
+  rec3 *mask;           // color_mask (12-byte records: k_logic is bound by the bytes it moves, most of them writes)
   float4 *total;        // total_color of the sample in flight, .w = s1 (raytracer.cuh:98)
   float4 *accum;        // sum of finished samples
-  float4 *dmask;        // color_mask at the hit whose shadow rays are in flight
+  rec3 *dmask;          // color_mask at the hit whose shadow rays are in flight
   float4 *ray_o, *ray_d, *hit;            // extension ray (origin|min_t, ctor direction|max_t) and its hit (t, b.y, b.z, idx)
-  float4 *sh_o, *sh_d, *sh_c;             // shadow rays, entry e = k * n_slots + slot, and their contributions
+  float4 *sh_o, *sh_d;                    // shadow rays: ONE origin per slot (the shadow rays of a hit all start at hit + bump,
+  rec3 *sh_c;                             //   raytracer.cuh:36-41), direction|max_t and contribution per entry e = k * n_slots + slot
   uint32_t *sh_occ;
   uint32_t *ext_queue, *sh_queue, *qcount;
   unsigned long long *ray_stats;          // closest, shadow, paths
@@ -89,6 +105,7 @@ struct TraceArgs {
   const float *verts;                     // 9 floats per primitive, flat order: the exact p1 p2 p3 (own-box test of k_trace_fast)
   const uint2 *big;                       // (start, count) of leaves with more than 15 primitives
   const float4 *ray_o, *ray_d;
+  uint32_t o_slots;                       // != 0: ray id's origin is ray_o[id % o_slots] (the shadow rays of a render: one origin per slot)
   const uint32_t *queue, *qcount;
   int qc_front, qc_back;                  // indices into qcount; qc_back < 0: no back range
   uint32_t qcap;                          // the back range ends at queue[qcap - 1]
