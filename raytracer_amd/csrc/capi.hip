@@ -178,6 +178,14 @@ struct mirt_scene {
   // work buffers (sized per render)
   DevBuf st, mask, total, accum, dmask, ray_o, ray_d, hit, sh_o, sh_d, sh_c, sh_occ, ext_queue, sh_queue, redo_q[2], mf_queue, live[2];
   DevBuf ctrl, ray_stats, out_accum, rgb, probe_idx, probe_t, any_t, planes;
+  std::vector<mirt_light> host_lights;   // for the table of constant shadow-ray directions (directional lights)
+  float const_dir[4] = {0, 0, 0, 0};     // rebuilt when samples_per_light changes
+  uint32_t const_dir_spl = 0, const_k = NO_CONST_K;
+  struct FillSig {                       // what the pre-filled sh_d records of entry const_k were written for (fill_constant_directions)
+    const void *buf = nullptr;
+    uint32_t pixel_slots = 0, streams = 0, K = 0, pipes = 0, k = 0, pad = 0;     // (no padding bytes: compared with memcmp)
+    float dir[4] = {0, 0, 0, 0};
+  } fill_sig;
   size_t device_bytes() const {
     const DevBuf *all[] = {&verts, &nodes4, &nodes2, &tris, &tri_nrm, &mats, &lights, &big, &trisf, &nodes8q, &st, &mask, &total, &accum, &dmask,
                            &ray_o, &ray_d, &hit, &sh_o, &sh_d, &sh_c, &sh_occ, &ext_queue, &sh_queue, &redo_q[0],
@@ -386,6 +394,7 @@ static int scene_create_impl(const float *tri_pos, const float *tri_nrm, const u
   s->n_tris = n_tris;
   s->n_mats = n_mats;
   s->n_lights = n_lights;
+  if (lights) s->host_lights.assign(lights, lights + n_lights);
 
   // triangles in the reference's flat order: (p1, e1, e2) for the intersector, (n1, n2, n3, material, original id) for shading
   std::vector<float> tri((size_t) n_tris * 12), nrm((size_t) n_tris * 12);
@@ -561,6 +570,7 @@ int scene_clone(const mirt_scene *src, mirt_scene **out) {
   s->fast_ok = src->fast_ok; s->own_builder = src->own_builder; s->n_nodes8 = src->n_nodes8; s->depth8 = src->depth8;
   memcpy(s->build_ms, src->build_ms, sizeof s->build_ms);
   s->ovf_depth = src->ovf_depth;
+  s->host_lights = src->host_lights;
   s->device = G.device;
   s->trace_threads = (uint32_t) (G.n_cu * G.blocks_per_cu * TRACE_BLOCK);
   const DevBuf mirt_scene::*data[] = {&mirt_scene::nodes4, &mirt_scene::nodes2, &mirt_scene::tris, &mirt_scene::tri_nrm, &mirt_scene::mats,
@@ -784,6 +794,7 @@ TraceArgs shadow_args(mirt_scene *s, uint32_t traversal, int pipe = 0, size_t ko
   unsigned long long *rs = s->ray_stats.as<unsigned long long>() + (size_t) pipe * 16;
   t.ray_o = s->sh_o.as<float4>() + (o_slots ? off : koff);
   t.o_slots = o_slots;
+
   t.ray_d = s->sh_d.as<float4>() + koff;
   t.queue = s->sh_queue.as<uint32_t>() + koff;
   t.qcount = ctrl + CTRL_QCOUNT;
@@ -913,6 +924,22 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   a.live_16th = G.live_16th;
   a.cull_zero = ((o.flags & 16u) && K >= 1 && K <= 32) ? 1u : 0u;
 
+  // shadow entry k = light * samples_per_light + j; entries towards a directional light need no direction record
+  if (K && s->const_dir_spl != prm->samples_per_light) {
+    s->const_k = NO_CONST_K;
+    for (uint32_t k = 0; k < K && s->const_k == NO_CONST_K; k++) {
+      const mirt_light &L = s->host_lights[k / prm->samples_per_light];
+      if (L.type == LIGHT_DIRECTIONAL) {
+        s->const_dir[0] = L.p[3]; s->const_dir[1] = L.p[4]; s->const_dir[2] = L.p[5];
+        s->const_dir[3] = std::numeric_limits<float>::infinity();      // dist - EPS_F with dist = INF (lights.cuh:96-101, raytracer.cuh:40)
+        s->const_k = k;
+      }
+    }
+    s->const_dir_spl = prm->samples_per_light;
+  }
+  if (getenv("MIRT_NO_CONST_DIR")) s->const_k = NO_CONST_K;          // (A/B: k_logic writes every shadow ray's direction record)
+  a.const_k = K ? s->const_k : NO_CONST_K;
+
   const bool profile = stats && (o.flags & 1u);
   const bool profile_closest = stats && (o.flags & 9u);                  // bit 3: time the closest-hit launches only
   const bool counting = stats && (o.flags & 2u);
@@ -992,6 +1019,19 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   uint32_t iters = 0;
   uint64_t n_camera = 0, n_bounced = 0, n_shadow_rays = 0, n_live = 0, n_scanned = 0;
   if (part.n_slots) {
+    // Entry const_k of every hit goes to a directional light: its direction records never change, so they are written once,
+    // here, and k_logic skips them (RenderArgs::const_k).  Again whenever the buffer, the slot layout or the light changed.
+    if (a.const_k != NO_CONST_K) {
+      mirt_scene::FillSig sig;
+      sig.buf = s->sh_d.p; sig.pixel_slots = part.n_slots; sig.streams = streams; sig.K = K; sig.pipes = (uint32_t) n_pipes; sig.k = a.const_k;
+      memcpy(sig.dir, s->const_dir, sizeof sig.dir);
+      if (memcmp(&sig, &s->fill_sig, sizeof sig) != 0) {
+        for (int p = 0; p < n_pipes; p++)
+          HIPCHK(launch_fill4(pipe[p].a.sh_d + (size_t) a.const_k * pipe[p].a.n_slots, pipe[p].a.n_slots,
+                              make_float4(s->const_dir[0], s->const_dir[1], s->const_dir[2], s->const_dir[3]), G.stream));
+        s->fill_sig = sig;
+      }
+    }
     if (n_pipes >= 2) {                                                  // the other pipes start after the clears above
       HIPCHK(hipEventRecord(G.pipe_ev[0], G.stream));
       for (int p = 1; p < n_pipes; p++) HIPCHK(hipStreamWaitEvent(G.pstream[p], G.pipe_ev[0], 0));
@@ -1301,6 +1341,7 @@ int mirt_trace(mirt_scene *s, const float *rays, uint32_t n, int any_hit, uint32
     HIPCHK(s->any_t.ensure((size_t) n * 4));
     HIPCHK(hipMemcpyAsync(s->sh_o.p, ro.data(), (size_t) n * 16, hipMemcpyHostToDevice, G.stream));
     HIPCHK(hipMemcpyAsync(s->sh_d.p, rd.data(), (size_t) n * 16, hipMemcpyHostToDevice, G.stream));
+    s->fill_sig.buf = nullptr;                               // (the pre-filled direction records of a render are gone)
     HIPCHK(launch_iota(s->sh_queue.as<uint32_t>(), n, G.stream));
     HIPCHK(hipMemcpyAsync(ctrl + CTRL_QCOUNT + QC_SHADOW, &n, 4, hipMemcpyHostToDevice, G.stream));
     t = shadow_args(s, traversal);

@@ -468,7 +468,8 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t 
 #if !MIRT_SHARED_ORIGIN
               a.sh_o[e] = make_float4(so.x, so.y, so.z, MIRT_EPS);
 #endif
-              a.sh_d[e] = make_float4(to_light.x, to_light.y, to_light.z, dist - MIRT_EPS);
+              if (k != a.const_k)                                  // (a directional light's rays: their records hold the light's direction already)
+                a.sh_d[e] = make_float4(to_light.x, to_light.y, to_light.z, dist - MIRT_EPS);
               a.sh_c[e] = mk_rec3(contrib.x, contrib.y, contrib.z);
             }
           }
@@ -750,7 +751,7 @@ __device__ __forceinline__ bool finite3(V3 v) {
 // SHARED: the launch may carry the shadow rays of a render (TraceArgs::o_slots).  Only the occlusion kernels are compiled with
 // it: in the closest-hit kernel the few extra instructions moved the register allocation from 72 to 77 VGPRs (one resident wave less).
 template<bool SHARED>
-__device__ __forceinline__ void load_ray(const TraceArgs &a, uint32_t id, LaneRay &r) {
+__device__ __forceinline__ void load_ray(const TraceArgs &a, uint32_t id, LaneRay &r, float *len2 = nullptr) {
   uint32_t oi = id;
   if (SHARED && a.o_slots && oi >= a.o_slots) {                 // shadow rays of a render: entry k * n_slots + slot starts at the slot's origin
     oi -= a.o_slots;
@@ -766,6 +767,7 @@ __device__ __forceinline__ void load_ray(const TraceArgs &a, uint32_t id, LaneRa
   r.b1 = 0; r.b2 = 0;
   r.best_idx = -1;
   r.id = id;
+  if (len2) *len2 = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;       // squared length of the ctor direction
 }
 
 // Sphere arm of Primitive::intersect / has_intersection (primitives.cuh:64-85, :111-136).  The two differ only in an
@@ -1132,7 +1134,8 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
           const uint32_t w = w_next + lane_rank(need);
           const uint32_t id = (w < w_end) ? ((w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)]) : QUEUE_SKIP;
           if (id != QUEUE_SKIP) {                          // (QUEUE_SKIP in the queue: a culled shadow ray)
-            load_ray<ANY>(a, id, r);
+            float l2;
+            load_ray<ANY>(a, id, r, &l2);
             // Slab and hit arithmetic stays finite for these rays; anything else (zero direction components -> 0 * inf,
             // non-finite origins, NaN bounds) makes the reference's result depend on its visiting order: defer to k_trace2.
             bool regular = finite3(r.o) && finite3(r.d) && finite3(r.inv) && (r.best_t == r.best_t) &&
@@ -1142,8 +1145,6 @@ __global__ void __launch_bounds__(TRACE_BLOCK) k_trace4(TraceArgs a) {
               // the normalised one (ray.cuh:19-21): unless the two agree (the integrator only makes unit directions) its
               // result depends on its own boxes and visiting order, so such rays take the reference walk (traversal 0
               // only: its tree is not the reference's).
-              const float4 rd = a.ray_d[id];
-              const float l2 = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
               regular = regular && (fabsf(l2 - 1.0f) < 1e-4f);
             }
             if (regular) {
@@ -1460,14 +1461,13 @@ __global__ void __launch_bounds__(TRACE_BLOCK) MIRT_TRACE_ATTR k_trace_fast(Trac
           const uint32_t w = w_next + lane_rank(need);
           const uint32_t id = (w < w_end) ? ((w < nA) ? a.queue[w] : a.queue[a.qcap - 1 - (w - nA)]) : QUEUE_SKIP;
           if (id != QUEUE_SKIP) {                          // (QUEUE_SKIP in the queue: a culled shadow ray)
-            load_ray<ANY>(a, id, r);
+            float l2;
+            load_ray<ANY>(a, id, r, &l2);
             // Rays the shortcut arithmetic is not meant for take the reference walk: non-finite origin / direction /
             // reciprocal (the reference's result then depends on its visiting order), a direction almost parallel to an
             // axis plane ((p - o) * inv would lose all precision), and ctor directions that are not unit length (the
             // reference prunes boxes along the un-normalised direction but measures hits along the normalised one,
             // ray.cuh:19-21; the integrator only makes unit directions).
-            const float4 rd = a.ray_d[id];
-            const float l2 = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
             const bool regular = finite3(r.o) && finite3(r.d) && (r.best_t == r.best_t) && (r.min_t == r.min_t) &&
                                  fabsf(r.inv.x) < INV_LIMIT && fabsf(r.inv.y) < INV_LIMIT && fabsf(r.inv.z) < INV_LIMIT &&
                                  (fabsf(l2 - 1.0f) < 1e-4f);
@@ -1704,6 +1704,10 @@ __global__ void k_gather_primary(RenderArgs a, int32_t *idx_out, uint32_t *tbits
   tbits_out[(size_t) py * a.width + px] = f2u(h.x);
 }
 
+__global__ void k_fill4(float4 *p, uint32_t n, float4 v) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
 __global__ void k_iota(uint32_t *q, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) q[i] = i;
@@ -1810,6 +1814,12 @@ hipError_t launch_probe_primary(const RenderArgs &a, hipStream_t st) {
 }
 hipError_t launch_gather_primary(const RenderArgs &a, int32_t *idx, uint32_t *tb, hipStream_t st) {
   k_gather_primary<<<(a.n_slots + 255) / 256, 256, 0, st>>>(a, idx, tb);
+  LAUNCH_CHECK();
+  return hipSuccess;
+}
+hipError_t launch_fill4(float4 *p, uint32_t n, float4 v, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  k_fill4<<<(n + 255) / 256, 256, 0, st>>>(p, n, v);
   LAUNCH_CHECK();
   return hipSuccess;
 }

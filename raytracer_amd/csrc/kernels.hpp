@@ -39,6 +39,7 @@ constexpr int CTR_STRIDE = 32;
 enum : int { QC_EXT_FRONT = 0, QC_EXT_BACK = CTR_STRIDE, QC_SHADOW = 2 * CTR_STRIDE, QC_LIVE = 3 * CTR_STRIDE,
              QC_CULLED = 4 * CTR_STRIDE, QC_WORDS = 5 * CTR_STRIDE };
 constexpr uint32_t QUEUE_SKIP = 0xFFFFFFFFu;   // a queue entry no ray stands behind (a culled shadow ray)
+constexpr uint32_t NO_CONST_K = 0xFFFFFFFFu;
 constexpr int WORK_PARTS = 8;        // a trace launch splits its queue into this many ranges, one fetch counter each
 
 struct RenderArgs {
@@ -77,6 +78,13 @@ struct RenderArgs {
   uint32_t *clear_next;                   // k_logic<false>: workgroup 0 zeroes the control block of the NEXT iteration (three
   uint32_t clear_words;                   //   blocks rotate, so that block is idle now), clear_words words of it
   uint32_t first;                         // k_logic<false>: the frame's first iteration - slots are initialised in place of k_init
+  // Shadow rays towards a DIRECTIONAL light all have the light's direction and no far limit.  For ONE entry of a hit - the
+  // first that goes to such a light, const_k (NO_CONST_K: none) - the host fills the sh_d records once (capi.hip,
+  // fill_constant_directions) and k_logic never writes them again: 16 bytes less to write per hit, and the traversal reads
+  // its ray records as before.  (Handing the direction to the traversal as an argument instead was tried first: a table
+  // in memory, four entries or one in the argument block - each made the occlusion kernel 25 - 30 % slower or cost it
+  // 40 VGPRs: any second source for the record changes the code around its refill, which runs every other trip.)
+  uint32_t const_k;
   // Share pool (mirt_options.shares = W > streams, counter RNG): a pixel's samples are cut into W contiguous shares, each summed
   // in sample order into a plane of its own (out_accum holds W planes, added in share order at the end), but only `streams`
   // slots per pixel slot exist.  A work item is (share, pixel slot) = share * n_pixel_slots + pixel slot; slot s starts with
@@ -131,6 +139,7 @@ hipError_t launch_logic(const RenderArgs &a, bool deferred_microfacet, hipStream
 hipError_t launch_probe_primary(const RenderArgs &a, hipStream_t st);
 hipError_t launch_gather_primary(const RenderArgs &a, int32_t *idx, uint32_t *tb, hipStream_t st);
 hipError_t launch_iota(uint32_t *q, uint32_t n, hipStream_t st);
+hipError_t launch_fill4(float4 *p, uint32_t n, float4 v, hipStream_t st);
 // mirt_trace_static: caller's n x 8 ray records (device) -> ray_o / ray_d / identity queue / queue counter, and back
 hipError_t launch_stage_rays(const float *rays8, uint32_t n, float4 *ray_o, float4 *ray_d, uint32_t *queue, uint32_t *qcount_slot,
                              hipStream_t st);
