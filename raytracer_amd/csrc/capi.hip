@@ -896,9 +896,14 @@ int render_impl(mirt_scene *s, const mirt_camera *camera, const mirt_params *prm
   RenderArgs a;
   memset(&a, 0, sizeof a);
   a.n_slots = (uint32_t) total_slots; a.n_pixel_slots = part.n_slots; a.streams = streams;
+  if (total_slots >= (1ull << 31) || (uint64_t) part.n_slots * shares >= (1ull << 31))
+    return fail(MIRT_E_LIMIT, "more than 2^31 path slots or share items");             // (fastdiv.hpp: dividends below 2^31)
   a.shares = shares; a.pool = pool ? 1u : 0u;
+  a.fd_pixel_slots = make_fastdiv(part.n_slots); a.fd_tiles_x = make_fastdiv(part.tiles_x);
+  a.share_len = (o.sample_count ? o.sample_count : prm->samples_per_pixel) / (shares ? shares : 1u);
   if (o.pool_group % 64u) return fail(MIRT_E_ARG, "pool_group must be a multiple of 64 (whole 8x8 tiles)");
   a.pool_group = o.pool_group ? o.pool_group : G.pool_group;
+  a.fd_pool_group = make_fastdiv(a.pool_group);
   a.pool_next = (uint32_t *) ((char *) s->ray_stats.p + RAY_STATS_BYTES + 256);
   const size_t pool_groups = pool ? ((size_t) part.n_slots + a.pool_group - 1) / a.pool_group : 0;
   a.width = w; a.height = h;
@@ -1296,6 +1301,7 @@ int mirt_primary_hits(mirt_scene *s, const mirt_camera *camera, const mirt_optio
   memset(&a, 0, sizeof a);
   a.n_slots = part.n_slots; a.width = w; a.height = h;
   a.tiles_x = part.tiles_x; a.tiles_y = part.tiles_y; a.tile_rank = 0; a.tile_world = 1;
+  a.fd_pixel_slots = make_fastdiv(part.n_slots); a.fd_tiles_x = make_fastdiv(part.tiles_x);
   a.rng_mode = o.rng_mode; a.seed = o.seed; a.spp = 1; a.batch = 2;
   a.cam = to_device_camera(*camera);
   a.st = s->st.as<uint4>(); a.mask = s->mask.as<rec3>(); a.total = s->total.as<float4>();

@@ -93,14 +93,14 @@ __device__ __forceinline__ void pslot_to_pixel(const RenderArgs &a, uint32_t psl
   // pixel slots are 8x8 pixel tiles (one wave = one tile); tiles are dealt round-robin over the processes of a tile partition
   const uint32_t tile_local = pslot >> 6, lane = pslot & 63;
   const uint32_t tile = tile_local * a.tile_world + a.tile_rank;
-  const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+  const uint32_t ty = fdiv(tile, a.fd_tiles_x), tx = tile - ty * a.tiles_x;
   px = tx * 8 + (lane & 7);
   py = ty * 8 + (lane >> 3);
   valid = (ty < a.tiles_y) && px < a.width && py < a.height;
 }
 __device__ __forceinline__ void slot_to_pixel(const RenderArgs &a, uint32_t slot, uint32_t &px, uint32_t &py, bool &valid) {
   // with sample streams the slot array repeats once per stream
-  pslot_to_pixel(a, a.streams > 1 ? slot % a.n_pixel_slots : slot, px, py, valid);
+  pslot_to_pixel(a, a.streams > 1 ? slot - fdiv(slot, a.fd_pixel_slots) * a.n_pixel_slots : slot, px, py, valid);
 }
 
 // ============================================================================================ k_init
@@ -142,9 +142,9 @@ __device__ __forceinline__ void item_share(const RenderArgs &a, uint32_t item, u
                                            uint32_t &count) {
   share = 0; pslot = item; first = 0; count = a.spp;
   if (a.shares > 1) {
-    share = item / a.n_pixel_slots;
+    share = fdiv(item, a.fd_pixel_slots);
     pslot = item - share * a.n_pixel_slots;
-    const uint32_t per = a.spp / a.shares;
+    const uint32_t per = a.share_len;
     first = share * per;
     count = (share == a.shares - 1) ? a.spp - per * (a.shares - 1) : per;     // (the pool needs spp % shares == 0: count == per)
   }
@@ -162,7 +162,7 @@ __device__ __forceinline__ uint32_t pool_group_size(const RenderArgs &a, uint32_
   return left < a.pool_group ? left : a.pool_group;
 }
 __device__ __forceinline__ uint32_t pool_item(const RenderArgs &a, uint32_t g, uint32_t size, uint32_t j) {
-  const uint32_t sh = j / size;
+  const uint32_t sh = size == a.pool_group ? fdiv(j, a.fd_pool_group) : j / size;     // (a ragged last group: plain division)
   return (a.streams + sh) * a.n_pixel_slots + g * a.pool_group + (j - sh * size);
 }
 
@@ -383,7 +383,7 @@ __device__ __forceinline__ void logic_slot(const RenderArgs &a0, const uint32_t 
           // the share is complete: its sum goes to the plane of the ACCUMULATOR's item (accum[].w), which is not the item of
           // the path in flight if that one was started ahead from the pool
           const uint32_t item_acc = f2u(acc4.w);
-          const uint32_t sh_acc = item_acc / a.n_pixel_slots;
+          const uint32_t sh_acc = fdiv(item_acc, a.fd_pixel_slots);
           uint32_t qx, qy;
           bool qv;
           pslot_to_pixel(a, item_acc - sh_acc * a.n_pixel_slots, qx, qy, qv);
@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(256) MIRT_LOGIC_ATTR k_logic(RenderArgs a) {
     uint32_t new_item = NO_ITEM, group = 0, group_size = 1;
     if (a.pool) {
       const bool asks = !T.skip && T.want == 2;
-      group = (s % a.n_pixel_slots) / a.pool_group;
+      group = fdiv(s - fdiv(s, a.fd_pixel_slots) * a.n_pixel_slots, a.fd_pool_group);
       group_size = pool_group_size(a, group);
       uint64_t m = __ballot(asks);
       while (m) {

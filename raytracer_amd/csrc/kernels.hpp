@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fastdiv.hpp"
 #include "host_bvh.hpp"
 #include "shade.hpp"
 
@@ -85,6 +86,9 @@ struct RenderArgs {
   // in memory, four entries or one in the argument block - each made the occlusion kernel 25 - 30 % slower or cost it
   // 40 VGPRs: any second source for the record changes the code around its refill, which runs every other trip.)
   uint32_t const_k;
+  // divisions k_logic does per slot and iteration, by multiplication (fastdiv.hpp; every dividend is below 2^31)
+  FastDiv fd_pixel_slots, fd_tiles_x, fd_pool_group;
+  uint32_t share_len;                     // spp / shares
   // Share pool (mirt_options.shares = W > streams, counter RNG): a pixel's samples are cut into W contiguous shares, each summed
   // in sample order into a plane of its own (out_accum holds W planes, added in share order at the end), but only `streams`
   // slots per pixel slot exist.  A work item is (share, pixel slot) = share * n_pixel_slots + pixel slot; slot s starts with
