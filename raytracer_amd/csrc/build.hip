@@ -387,6 +387,7 @@ __global__ void __launch_bounds__(BLOCK) k_ploc_relabel(uint32_t n, const uint32
 // that becomes wide node base + e; inner children are appended to the next level's queue, whose position is their index.
 struct Fold {
   uint32_t n, max_leaf;
+  float leaf_ct;                                            // what dividing a would-be leaf costs, in primitive tests (MIRT_SAH_LEAF_CT)
   const uint32_t *sorted;
   Boxes prim;
   const uint2 *child, *range;
@@ -420,6 +421,25 @@ __device__ __forceinline__ uint32_t fold_first(const Fold &f, uint32_t ref) {
   return (ref & LEAF_BIT) ? (ref & ~LEAF_BIT) : f.range[ref].x;
 }
 
+__device__ __forceinline__ float fold_area(const Fold &f, uint32_t ref) {
+  float lo[3], hi[3];
+  fold_box(f, ref, lo, hi);
+  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+// A subtree of at most max_leaf primitives becomes a leaf unless dividing it where the binary tree does still pays: the same
+// rule as the host builder's (host_bvh.cpp, SahBuilder::build), which searches for the division; here it is the tree's own.
+__device__ __forceinline__ bool fold_is_leaf(const Fold &f, uint32_t ref) {
+  const uint32_t cnt = fold_count(f, ref);
+  if (cnt > f.max_leaf) return false;
+  if (cnt < 2 || !(f.leaf_ct < 1.0e9f)) return true;
+  const float a = fold_area(f, ref);
+  if (!(a > 0.f)) return true;
+  const uint2 c = f.child[ref];
+  const float divided = fold_area(f, c.x) * (float) fold_count(f, c.x) + fold_area(f, c.y) * (float) fold_count(f, c.y);
+  return !(f.leaf_ct * a + divided < (float) cnt * a);
+}
+
 __global__ void __launch_bounds__(64) k_fold_level(Fold f) {
   const uint32_t e = blockIdx.x * 64 + threadIdx.x;
   if (e >= f.count) return;
@@ -429,16 +449,9 @@ __global__ void __launch_bounds__(64) k_fold_level(Fold f) {
   int nk = 0;
   auto add = [&](int k, uint32_t ref) {
     kids[k] = ref;
-    if (fold_count(f, ref) <= f.max_leaf) {
-      area[k] = -1.f;
-    } else {
-      float lo[3], hi[3];
-      fold_box(f, ref, lo, hi);
-      const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-      area[k] = dx * dy + dy * dz + dz * dx;
-    }
+    area[k] = fold_is_leaf(f, ref) ? -1.f : fold_area(f, ref);
   };
-  if (fold_count(f, root) <= f.max_leaf) {
+  if (fold_is_leaf(f, root)) {
     add(nk++, root);                                        // a scene that is one leaf
   } else {
     const uint2 c = f.child[root];
@@ -501,7 +514,7 @@ __global__ void __launch_bounds__(64) k_fold_level(Fold f) {
   for (int k = 0; k < 8; k++) words[4 + k] = CHILD_EMPTY;
   for (int k = 0; k < nk; k++) {
     const uint32_t cnt = fold_count(f, kids[k]);
-    if (cnt <= f.max_leaf) {
+    if (fold_is_leaf(f, kids[k])) {
       words[4 + k] = CHILD_LEAF | (cnt << LEAF_COUNT_SHIFT) | fold_first(f, kids[k]);
     } else {
       const uint32_t pos = atomicAdd(&f.next_count[0], 1u);
@@ -718,6 +731,8 @@ int build_fast_tree_device(const float *pos_flat_host, const uint8_t *ptype_flat
   Fold fd{};
   fd.n = n;
   fd.max_leaf = max_leaf;
+  fd.leaf_ct = 0.5f;
+  if (const char *e = std::getenv("MIRT_SAH_LEAF_CT")) fd.leaf_ct = (float) std::atof(e);
   fd.sorted = t_sorted;
   fd.prim = bx;
   fd.child = t_child;

@@ -482,6 +482,8 @@ struct SahBuilder {
   uint32_t max_leaf;
   static constexpr int MAX_BINS = 64;
   int BINS = 16;                          // MIRT_SAH_BINS
+  float leaf_ct = 0.5f;                   // MIRT_SAH_LEAF_CT: what dividing a would-be leaf costs, in primitive tests (1e30 = never divide, the
+                                          // rule until round 3: conference* -1.5 %, bunny* -2.5 %, buddha* -3.4 %, sportsCar* -3.9 %, tools/leaf_sweep.sh)
   float peel = 0.5f;                      // primitives whose box area exceeds peel x the node's go into a subtree of their own
                                           // (0 = off; tools/peel_sweep.sh: conference* 135.7 -> 133.3 ms/frame)
 
@@ -566,8 +568,56 @@ struct SahBuilder {
     for (int k = 0; k < 3; k++) { out[id].minp[k] = bb.lo[k]; out[id].maxp[k] = bb.hi[k]; }
     const uint32_t n = e - s;
     if (n <= max_leaf) {
-      out[id].w0 = 0x80000000u | n;
-      out[id].w1 = s;
+      // Few enough for a leaf - unless dividing them still pays.  The traversal tests a leaf's primitives one per trip, the
+      // price of a node step, and the fold to 8-wide nodes mostly absorbs a split at this level into the parent's free child
+      // slots: so a leaf of n costs n tests, a split leaf_ct + the area-weighted tests of its halves.  Every division of the
+      // (at most 15) primitives along their centroid order on each axis is tried.
+      uint32_t cut = 0;
+      if (n >= 2 && leaf_ct < 1.0e9f && area(bb) > 0.f) {
+        uint32_t best_idx[LEAF_MAX];
+        float best_cost = std::numeric_limits<float>::infinity();
+        for (int ax = 0; ax < 3; ax++) {
+          uint32_t idx[LEAF_MAX];
+          for (uint32_t i = 0; i < n; i++) idx[i] = order[s + i];
+          for (uint32_t i = 1; i < n; i++) {               // insertion sort by (centroid, index)
+            const uint32_t v = idx[i];
+            const float cv = cent[3 * (size_t) v + ax];
+            uint32_t j = i;
+            while (j > 0 && (cent[3 * (size_t) idx[j - 1] + ax] > cv || (cent[3 * (size_t) idx[j - 1] + ax] == cv && idx[j - 1] > v))) {
+              idx[j] = idx[j - 1];
+              j--;
+            }
+            idx[j] = v;
+          }
+          float ra[LEAF_MAX];
+          Box acc = empty();
+          for (uint32_t k = n - 1; k > 0; k--) { grow(acc, pbox[idx[k]]); ra[k] = area(acc); }
+          acc = empty();
+          for (uint32_t k = 1; k < n; k++) {
+            grow(acc, pbox[idx[k - 1]]);
+            const float cost = area(acc) * (float) k + ra[k] * (float) (n - k);
+            if (cost < best_cost) {
+              best_cost = cost;
+              cut = k;
+              for (uint32_t i = 0; i < n; i++) best_idx[i] = idx[i];
+            }
+          }
+        }
+        if (cut != 0 && leaf_ct * area(bb) + best_cost < (float) n * area(bb)) {
+          for (uint32_t i = 0; i < n; i++) order[s + i] = best_idx[i];
+        } else {
+          cut = 0;
+        }
+      }
+      if (cut == 0) {
+        out[id].w0 = 0x80000000u | n;
+        out[id].w1 = s;
+        return id;
+      }
+      const uint32_t l = build(s, s + cut, depth + 1);
+      const uint32_t r = build(s + cut, e, depth + 1);
+      out[id].w0 = l;
+      out[id].w1 = r;
       return id;
     }
     // Primitives that span most of the node (a room's walls around its furniture) would inflate whichever half they fall
@@ -663,6 +713,69 @@ struct Collapser8 {
   uint32_t max_depth = 0;
   explicit Collapser8(const Pool<Node2> &nodes) : n2(nodes) {}
 
+  // Which binary nodes become 8-wide nodes: the choice that minimises the summed surface area of the wide nodes (the
+  // expected number of node steps of a random ray; the leaves are the binary tree's, so their cost is the same whatever is
+  // chosen).  Dynamic programme over the binary tree (Ylitie, Karras, Laine 2017, section 4.1, with fixed leaves):
+  //   c(n, i)  = least cost of handing the subtree of n to its ancestor as at most i children, i = 1..7
+  //   d(n, j)  = min over k of c(left, k) + c(right, j - k): n dissolved, its two sides share j slots, j = 2..8
+  //   c(n, 1)  = area(n) + d(n, 8)   (n becomes a wide node of its own);   c(n, i) = min(d(n, i), c(n, i - 1))
+  // Measured (tools/fold_ab.sh, profiles/r3d_fold_ab.txt): 37 % fewer wide nodes on conference*, and no gain on any workload
+  // (node visits 4.31 -> 4.07 but primitive tests 2.60 -> 2.83 there, both up on the other three): leaves pulled up into
+  // large nodes get their boxes on that node's coarse 8-bit grid.  Off by default; MIRT_FOLD_DP=1 turns it on.
+  bool optimal = false;                                  // false: the greedy rule (largest-area child dissolved first)
+  std::vector<float> cst;                                // [node][7]
+  std::vector<uint8_t> kk;                               // [node][7]: the k of d(n, j), j = 2..8
+  std::vector<uint8_t> from_d;                           // [node]: bit i set if c(n, i) = d(n, i) < c(n, i - 1)
+  void plan(uint32_t n) {
+    const Node2 &nd = n2[n];
+    if (nd.w0 & 0x80000000u) {
+      for (int i = 0; i < 7; i++) cst[7 * (size_t) n + i] = 0.f;
+      return;
+    }
+    plan(nd.w0);
+    plan(nd.w1);
+    const float *cl = &cst[7 * (size_t) nd.w0], *cr = &cst[7 * (size_t) nd.w1];
+    float d[9];
+    for (int j = 2; j <= 8; j++) {
+      float best = std::numeric_limits<float>::infinity();
+      int bk = 1;
+      for (int k = (j - 7 > 1 ? j - 7 : 1); k <= (j - 1 < 7 ? j - 1 : 7); k++) {
+        const float v = cl[k - 1] + cr[j - k - 1];
+        if (v < best) { best = v; bk = k; }
+      }
+      d[j] = best;
+      kk[7 * (size_t) n + (j - 2)] = (uint8_t) bk;
+    }
+    float *c = &cst[7 * (size_t) n];
+    c[0] = d[8] + half_area(nd);
+    uint8_t bits = 0;
+    for (int i = 2; i <= 7; i++) {
+      if (d[i] < c[i - 2]) { c[i - 1] = d[i]; bits |= (uint8_t) (1u << i); }
+      else c[i - 1] = c[i - 2];
+    }
+    from_d[n] = bits;
+  }
+  void place(uint32_t n, int i, uint32_t *kids, int &nk) const {      // the subtree of n as at most i children
+    const Node2 &nd = n2[n];
+    if (!(nd.w0 & 0x80000000u)) {
+      while (i > 1 && !((from_d[n] >> i) & 1u)) i--;
+      if (i > 1) { expand(n, i, kids, nk); return; }
+    }
+    kids[nk++] = n;
+  }
+  void expand(uint32_t n, int j, uint32_t *kids, int &nk) const {     // n dissolved into j slots
+    const int k = kk[7 * (size_t) n + (j - 2)];
+    place(n2[n].w0, k, kids, nk);
+    place(n2[n].w1, j - k, kids, nk);
+  }
+  void prepare(uint32_t root_id) {
+    if (!optimal) return;
+    cst.assign(7 * n2.size(), 0.f);
+    kk.assign(7 * n2.size(), 1);
+    from_d.assign(n2.size(), 0);
+    plan(root_id);
+  }
+
   uint32_t build(uint32_t root_id, uint32_t depth) {
     const uint32_t id = (uint32_t) out.size();
     out.emplace_back();
@@ -672,6 +785,8 @@ struct Collapser8 {
     int nk = 0;
     if (root.w0 & 0x80000000u) {
       kids[nk++] = root_id;                              // a scene that is one leaf
+    } else if (optimal) {
+      expand(root_id, 8, kids, nk);
     } else {
       kids[nk++] = root.w0;
       kids[nk++] = root.w1;
@@ -758,13 +873,14 @@ void build_fast_tree(const float *tri_pos_flat, const uint8_t *prim_type_flat, u
   SahBuilder sb(n2, bvh.fast_to_flat);
   sb.pos = tri_pos_flat;
   sb.ptype = prim_type_flat;
-  sb.max_leaf = 3;                                         // measured best of 1..8 on the bench workload (tools/sweep.sh MIRT_FAST_LEAF)
+  sb.max_leaf = 3;                                         // measured best of 1..8 on the bench workload (tools/leaf_sweep.sh, with leaf_ct)
   if (const char *e = std::getenv("MIRT_FAST_LEAF")) {     // tuning knob (1..15: the inline leaf count field)
     int v = std::atoi(e);
     if (v >= 1 && v <= (int) LEAF_MAX) sb.max_leaf = (uint32_t) v;
   }
   StageClock clk;
   if (const char *e = std::getenv("MIRT_SAH_PEEL")) sb.peel = (float) std::atof(e);
+  if (const char *e = std::getenv("MIRT_SAH_LEAF_CT")) sb.leaf_ct = (float) std::atof(e);
   if (const char *e = std::getenv("MIRT_SAH_BINS")) {
     int v = std::atoi(e);
     if (v >= 2 && v <= SahBuilder::MAX_BINS) sb.BINS = v;
@@ -775,6 +891,8 @@ void build_fast_tree(const float *tri_pos_flat, const uint8_t *prim_type_flat, u
   clk.lap("own tree: binned SAH");
   bvh.fast_to_flat = sb.order;
   Collapser8 c8(n2);
+  if (const char *e = std::getenv("MIRT_FOLD_DP")) c8.optimal = std::atoi(e) != 0;
+  c8.prepare(0);
   c8.build(0, 0);
   clk.lap("own tree: fold to 8-wide");
   bvh.depth8 = c8.max_depth;
