@@ -17,7 +17,7 @@ Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the clos
 peak: algorithmic bytes = rays x (160 B of wavefront state + node visits x 96 B + triangle tests x 48 B),
 time = that kernel's launches measured with HIP events on its own stream inside the timed steps; `roofline.kernels` prices
 all three hot kernels, `roofline.frame` adds up the measured HBM traffic of the whole frame, `roofline.sq` quotes the issue /
-lane / wait fractions of the traversal kernels from the committed counter passes (profiles/r3c_pmc_sq.json).
+lane / wait fractions of the traversal kernels from the committed counter passes (profiles/r3d_pmc_sq.json).
 `cpu_baseline` times the reference's own CPU path (oracle/_ref, built from /root/reference in the build container) -- or the
 C oracle when that library is absent -- on a bounded crop of the same workload, on the box's host cores.
 """
@@ -189,10 +189,10 @@ def traffic_table(args, world):
 
 def sq_table(args, world):
     """Issue / lane / wait fractions of the hot kernels from the committed SQ counter passes (tools/pmc_run.sh on the bench
-    configuration -> profiles/r3c_pmc_sq.csv -> tools/pmc_sq_json.py -> profiles/r3c_pmc_sq.json).  None when absent or when
+    configuration -> profiles/r3d_pmc_sq.csv -> tools/pmc_sq_json.py -> profiles/r3d_pmc_sq.json).  None when absent or when
     it was collected for another workload / traversal."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r3c_pmc_sq.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r3d_pmc_sq.json")) as fh:
             d = json.load(fh)
         c = d.get("configuration", {})
         if (c.get("workload"), c.get("traversal"), c.get("n_gpus")) != (args.workload, args.traversal, world):
