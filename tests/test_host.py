@@ -116,6 +116,35 @@ def test_quantised_tree_boxes_contain_their_primitives(make):
     assert depth == b["depth8"]
 
 
+def _leaf_sizes(nodes8q):
+    refs = np.asarray(nodes8q).reshape(-1, 24)[:, 4:12].ravel()
+    leaves = refs[(refs != 0xFFFFFFFF) & ((refs & 0x80000000) != 0)]
+    return np.bincount((leaves >> 27) & 15, minlength=4)
+
+
+def test_would_be_leaves_are_divided_where_it_pays(monkeypatch):
+    """host_bvh.cpp, SahBuilder::build: n <= 3 primitives stay one leaf only if n <= 0.5 + the area-weighted count of their
+    best division (MIRT_SAH_LEAF_CT; 1e30 = the fixed rule of rounds 1 - 2).  Same primitives either way, valid trees, fewer
+    primitives per leaf with the rule; on two triangles far apart the division always pays, on two coincident ones never."""
+    from treecheck import check_own_tree
+    sc = scenes.conference_scene(20000)
+    sizes = {}
+    for ct in ("1e30", "0.5"):
+        monkeypatch.setenv("MIRT_SAH_LEAF_CT", ct)
+        b = capi.bvh_build_host(sc.pos, 4, sc.ptype)
+        check_own_tree(b["nodes8q"], b["fast_to_flat"], sc.pos[b["flat"]], np.zeros(sc.n, bool), sc.n)
+        h = _leaf_sizes(b["nodes8q"])
+        assert (h * np.arange(len(h))).sum() == sc.n
+        sizes[ct] = (h * np.arange(len(h))).sum() / h.sum()
+    assert sizes["0.5"] < sizes["1e30"]
+    monkeypatch.delenv("MIRT_SAH_LEAF_CT")
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    apart = np.stack([tri, tri + np.float32(100.0)])
+    same = np.stack([tri, tri])
+    assert _leaf_sizes(capi.bvh_build_host(apart, 4)["nodes8q"])[1] == 2          # two leaves of one
+    assert _leaf_sizes(capi.bvh_build_host(same, 4)["nodes8q"])[2] == 1           # one leaf of two
+
+
 def test_single_leaf_scene():
     sc = scenes.random_soup(3, 1)
     b = capi.bvh_build_host(sc.pos, 4)
