@@ -77,6 +77,9 @@ def parse(argv=None):
     ap.add_argument("--cull-zero", action="store_true",
                     help="do not trace shadow rays whose contribution is exactly zero (same film, fewer rays; off by default: "
                          "the headline counts the rays the reference's control flow traces)")
+    ap.add_argument("--no-film", action="store_true",
+                    help="leave the film hand-over (tonemap, PCIe, widening) out of the step: what a rank other than 0 of an N-rank frame "
+                         "runs; for pricing per-rank shares on one GPU (DESIGN.md 6), not a bench line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args(argv)
@@ -328,7 +331,7 @@ def main(argv=None, backend_cls=GpuBackend, script=None):
         st = rdist.render_partitioned(lambda acc, **part: be.render_accum(acc, **{**opt, **part}),
                                       accum, dist, rank, world, args.partition, args.spp, via_host=args.backend == "gloo",
                                       sync=be.sync)
-        if rank == 0:
+        if rank == 0 and not args.no_film:
             be.tonemap(accum)
         return st
 
@@ -440,7 +443,8 @@ def report(be, args, opt, stats, rays, ms_per_step, world, accum):
         "config": {"workload": f"{args.workload} {sd.n} tris, {w}x{h}, {args.spp} spp, depth {args.depth}, "
                                f"{len(sd.lights)} light{'s' if len(sd.lights) != 1 else ''}, rng {'counter' if opt['rng_mode'] else 'xorshift'}, "
                                f"traversal {args.traversal}, {opt['streams']} sample streams"
-                               + (f", pool of {opt['shares']} shares" if opt.get("shares") else ""),
+                               + (f", pool of {opt['shares']} shares" if opt.get("shares") else "")
+                               + (", WITHOUT the film hand-over (--no-film: a share, not a frame)" if args.no_film else ""),
                    "partition": f"{args.partition} x{world}", "rays_per_frame": rays / max(1, args.steps),
                    "reference_walk_rays_per_frame": sum(s["exact_fallback_rays"] for s in stats) / max(1, args.steps),
                    "scene_build_s": be.build_s, "builder": args.builder or "host", "build_ms": be.build_ms},
